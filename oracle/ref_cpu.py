@@ -1,0 +1,422 @@
+"""CPU oracle for the DDPM hot path (TEST INFRASTRUCTURE, not product code).
+
+A functional, fp32, pure-torch restatement of the reference's UNet denoiser,
+diffusion schedule, forward noising, ancestral reverse step and ELBO objective.
+It exists only so that tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg can check (and time) the HIP path against the reference's
+arithmetic.  Nothing in the product package may import this module.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here
+against tests/golden/*.pt, which tools/gen_golden.py produced by importing the
+reference itself (CPU, fp32) in the build container.
+
+Parameters are passed as a flat dict {state_dict key: tensor} using exactly the
+reference's key names ("model.encoder.stem_layers.0.weight", ...), so a
+reference checkpoint can be evaluated directly.  Each function cites the
+reference lines it restates.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------- config
+@dataclass
+class UNetCfg:
+    """Constructor keywords of the denoiser (reference experiments_setup/configs/DDPM.yaml:4-20).
+
+    time_norm is the constant the raw timestep is divided by before the sinusoidal
+    embedding.  The reference never forwards the YAML's T to the UNet, so its
+    UNetHolder default applies (neural_nets/denoise_models/dm_utils.py:46): 100.
+    """
+    img_channels: int = 3
+    stages_channels: Sequence[int] = (32, 64, 128, 256)
+    latent_dim: int = 512
+    expand_factor: int = 2
+    drop_p: float = 0.1
+    t_embed_dim: int = 32
+    activation: str = "gelu"
+    base_groups_norm: int = 4
+    time_norm: float = 100.0
+
+    @property
+    def groups(self) -> int:          # constituent_blocks.py:68-72, conv_block.py:67-71
+        return 4 * self.base_groups_norm
+
+    @property
+    def latent_groups(self) -> int:   # unets.py:80-84
+        return 8 * self.base_groups_norm
+
+
+def act_fn(name: str):
+    """Parameter-free activations of the reference registry (neural_nets/activations.py:102-114)."""
+    table = {
+        "gelu": lambda x: F.gelu(x, approximate="none"),
+        "silu": F.silu,
+        "relu": F.relu,
+        "relu6": F.relu6,
+        "sigmoid": torch.sigmoid,
+        "tanh": torch.tanh,
+        "hardsigmoid": F.hardsigmoid,
+        "leaky_relu": lambda x: F.leaky_relu(x, 0.05),
+        "selu": F.selu,
+    }
+    return table[name]
+
+
+# --------------------------------------------------------------------------- schedule
+def make_schedule(T: int, beta: float = 0.25, device="cpu") -> Dict[str, Tensor]:
+    """The nine (T+1,1,1,1) fp32 tables of DDPM.__init__ (ddpm.py:44-62), same op order."""
+    betas = torch.linspace(0.0, beta, steps=T + 1, device=device).view(T + 1, 1, 1, 1)
+    alphas = 1.0 - betas
+    alphas_bar = torch.cumprod(alphas, dim=0)
+    one_minus = 1.0 - alphas_bar
+    return {
+        "betas": betas,
+        "alphas": alphas,
+        "alphas_bar": alphas_bar,
+        "sqrt_alphas_bar": torch.sqrt(alphas_bar),
+        "square_betas": betas ** 2,
+        "one_minus_alphas_bar": one_minus,
+        "square_one_minus_alphas_bar": one_minus ** 2,
+        "sqrt_one_minus_alphas_bar": torch.sqrt(one_minus),
+        "x_previous_coef": torch.sqrt(alphas) / one_minus,
+        "x0_pred_coef": betas / one_minus,
+        "bw_std": torch.sqrt(betas / one_minus),
+    }
+
+
+def q_sample(s: Dict[str, Tensor], x0: Tensor, t: Tensor, noise: Tensor) -> Tensor:
+    """x_t = sqrt(abar_t) x0 + sqrt(1-abar_t) eps   (ddpm.py:102-106)."""
+    t = t.int()
+    mean = s["sqrt_alphas_bar"][t] * x0
+    return mean + s["sqrt_one_minus_alphas_bar"][t] * noise
+
+
+def reverse_step(s: Dict[str, Tensor], x_t: Tensor, x0_pred: Tensor, t: Tensor, z: Tensor) -> Tensor:
+    """x0-form posterior sample (ddpm.py:138-144), same association order."""
+    t = t.int()
+    mean_prev = (
+        s["one_minus_alphas_bar"][t - 1] * s["x_previous_coef"][t] * x_t
+        + s["sqrt_alphas_bar"][t - 1] * s["x0_pred_coef"][t] * x0_pred
+    )
+    return mean_prev + s["sqrt_one_minus_alphas_bar"][t - 1] * s["bw_std"][t] * z
+
+
+def elbo_weight(s: Dict[str, Tensor], t: Tensor, eps: float = 1e-4) -> Tensor:
+    """Per-sample weight w_t of ELBOLoss (losses/ELBO.py:66-67), shape (N,1,1,1)."""
+    vars_t = (s["sqrt_one_minus_alphas_bar"][t - 1] * s["bw_std"][t]) ** 2
+    return 0.5 * s["square_betas"][t] * s["alphas_bar"][t - 1] / (vars_t * s["square_one_minus_alphas_bar"][t] + eps)
+
+
+def elbo_loss(s: Dict[str, Tensor], t: Tensor, x_pred: Tensor, x_in: Tensor,
+              method: str = "mse", use_elbo: bool = True, eps: float = 1e-4) -> Tensor:
+    """ELBOLoss.forward (losses/ELBO.py:61-76) -> 0-d tensor."""
+    fn = F.mse_loss if method == "mse" else F.binary_cross_entropy_with_logits
+    if not use_elbo:
+        return fn(x_pred, x_in)
+    w = elbo_weight(s, t, eps)
+    return (fn(x_pred, x_in, reduction="none") * w.expand_as(x_in)).mean()
+
+
+# --------------------------------------------------------------------------- blocks
+def sinusoidal(t_norm: Tensor, dim: int) -> Tensor:
+    """SinusoidalPositionEmbedBlock.forward (constituent_blocks.py:261-279)."""
+    half = dim // 2
+    pre = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half, device=t_norm.device) * -pre)
+    arg = t_norm.view(-1, 1) * freq[None, :]
+    return torch.cat((arg.sin(), arg.cos()), dim=-1)
+
+
+def embed_block(p: Params, pre: str, temb: Tensor, act) -> Tensor:
+    """EmbedBlock: Linear -> act -> Linear -> (N,C,1,1)   (constituent_blocks.py:308-328)."""
+    h = F.linear(temb, p[pre + "layers.0.weight"], p[pre + "layers.0.bias"])
+    h = F.linear(act(h), p[pre + "layers.2.weight"], p[pre + "layers.2.bias"])
+    return h[:, :, None, None]
+
+
+class DropMasks:
+    """Pre-drawn keep masks so a dropout site can be replayed identically by another
+    implementation.  masks[i] multiplies the input of the i-th dropout site in call
+    order and already contains the 1/(1-p) scale.  Empty => dropout disabled."""
+
+    def __init__(self, masks: Optional[List[Tensor]] = None):
+        self.masks = masks or []
+        self.i = 0
+
+    def __call__(self, x: Tensor) -> Tensor:
+        if not self.masks:
+            return x
+        m = self.masks[self.i]
+        self.i += 1
+        return x * m
+
+
+def conv_gn_act(p: Params, conv: str, gn: str, x: Tensor, groups: int, act, *, stride=1, transposed=False) -> Tensor:
+    """Conv(3x3 | convT 2x2 s2) -> GroupNorm -> activation triple (constituent_blocks.py:65-74,166-188)."""
+    if transposed:
+        y = F.conv_transpose2d(x, p[conv + "weight"], p[conv + "bias"], stride=2)
+    else:
+        y = F.conv2d(x, p[conv + "weight"], p[conv + "bias"], stride=stride, padding=1)
+    y = F.group_norm(y, groups, p[gn + "weight"], p[gn + "bias"], eps=1e-5)
+    return act(y)
+
+
+def sir_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
+    """SeparableInvertResidual.forward (conv_block.py:57-136): three conv+GN stages, each fed a
+    dropped-out input; the residual adds the un-dropped block input."""
+    e = F.conv2d(drop(x), p[pre + "expansion.1.weight"], p[pre + "expansion.1.bias"])
+    e = act(F.group_norm(e, groups, p[pre + "expansion.2.weight"], p[pre + "expansion.2.bias"], eps=1e-5))
+    c = e.shape[1]
+    d = F.conv2d(drop(e), p[pre + "depthwise.1.weight"], p[pre + "depthwise.1.bias"], padding=1, groups=c)
+    d = act(F.group_norm(d, groups, p[pre + "depthwise.2.weight"], p[pre + "depthwise.2.bias"], eps=1e-5))
+    o = F.conv2d(drop(d), p[pre + "projection.1.weight"], p[pre + "projection.1.bias"])
+    o = F.group_norm(o, groups, p[pre + "projection.2.weight"], p[pre + "projection.2.bias"], eps=1e-5)
+    if o.shape == x.shape:
+        o = o + x
+    return o
+
+
+def down_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
+    """DownBlock.forward (constituent_blocks.py:63-90,135-147)."""
+    z = conv_gn_act(p, pre + "layers.0.0.", pre + "layers.0.1.", x, groups, act, stride=2)
+    z = sir_block(p, pre + "layers.1.", z, groups, act, drop)
+    z = sir_block(p, pre + "layers.2.", z, groups, act, drop)
+    return conv_gn_act(p, pre + "layers.3.0.", pre + "layers.3.1.", z, groups, act)
+
+
+def up_block(p: Params, pre: str, x: Tensor, skip: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
+    """UpBlock.forward (constituent_blocks.py:165-193,227-243)."""
+    z = torch.cat([x, skip], dim=1)
+    z = conv_gn_act(p, pre + "layers.0.0.", pre + "layers.0.1.", z, groups, act)
+    z = sir_block(p, pre + "layers.1.", z, groups, act, drop)
+    z = conv_gn_act(p, pre + "layers.2.0.", pre + "layers.2.1.", z, groups, act, transposed=True)
+    z = sir_block(p, pre + "layers.3.", z, groups, act, drop)
+    return sir_block(p, pre + "layers.4.", z, groups, act, drop)
+
+
+# --------------------------------------------------------------------------- UNet
+def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: str = "model.",
+                 drop: Optional[DropMasks] = None, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """BaseUNet.forward = decoder(encoder(x, t), skips, t)   (unets.py:100-132,206-240,250-273).
+
+    taps, when given, is filled with named intermediate tensors (stage outputs, latent,
+    pre-Tanh logits) so per-layer parity can be checked."""
+    act = act_fn(cfg.activation)
+    drop = drop or DropMasks()
+    g = cfg.groups
+    nst = len(cfg.stages_channels)
+    enc, dec = prefix + "encoder.", prefix + "decoder."
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+        return v
+
+    # ---- encoder (unets.py:121-132)
+    temb = sinusoidal(time.float() / cfg.time_norm, cfg.t_embed_dim)
+    z = act(F.conv2d(x, p[enc + "stem_layers.0.weight"], p[enc + "stem_layers.0.bias"], padding=1))
+    tap("enc.stem", z)
+    skips = []
+    for i in range(nst):
+        z = down_block(p, f"{enc}layers.{i}.", z + embed_block(p, f"{enc}t_embeddings.{i}.", temb, act), g, act, drop)
+        skips.append(tap(f"enc.stage{i}", z))
+    z = F.conv2d(z, p[enc + "latent_layers.0.weight"], p[enc + "latent_layers.0.bias"], padding=1)
+    z = act(F.group_norm(z, cfg.latent_groups, p[enc + "latent_layers.1.weight"], p[enc + "latent_layers.1.bias"], eps=1e-5))
+    tap("enc.latent", z)
+
+    # ---- decoder (unets.py:230-240)
+    z = conv_gn_act(p, dec + "decoder_input_layers.0.", dec + "decoder_input_layers.1.", z, g, act)
+    tap("dec.input", z)
+    skips = skips[::-1]
+    for i in range(nst):
+        z = up_block(p, f"{dec}layers.{i}.", z + embed_block(p, f"{dec}t_embeddings.{i}.", temb, act), skips[i], g, act, drop)
+        tap(f"dec.stage{i}", z)
+    z = act(F.conv2d(z, p[dec + "out_layers.0.weight"], p[dec + "out_layers.0.bias"], padding=1))
+    z = F.conv2d(z, p[dec + "out_layers.2.weight"], p[dec + "out_layers.2.bias"], padding=1)
+    tap("dec.logits", z)
+    return torch.tanh(z)
+
+
+def count_dropout_sites(cfg: UNetCfg) -> int:
+    """3 per inverted-residual block; 2 per down stage + 3 per up stage (conv_block.py:57-58,77-78,100-101)."""
+    return 3 * 5 * len(cfg.stages_channels)
+
+
+def draw_drop_masks(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, gen: torch.Generator) -> List[Tensor]:
+    """Draw one Bernoulli keep mask (scaled by 1/(1-p)) per dropout site, in call order,
+    with the shapes a forward pass presents to each site."""
+    shapes: List[torch.Size] = []
+
+    class _Rec(DropMasks):
+        def __call__(self, v):
+            shapes.append(v.shape)
+            return v
+
+    with torch.no_grad():
+        unet_forward(p, cfg, x, time, drop=_Rec())
+    keep = 1.0 - cfg.drop_p
+    return [(torch.rand(s, generator=gen) < keep).float() / keep for s in shapes]
+
+
+# --------------------------------------------------------------------------- conditional module (never instantiated by the reference UNet)
+def conditional_module(p: Params, pre: str, query: Tensor, cond: Tensor, depth: int, act, num_heads: int = 8) -> Tensor:
+    """ConditionalModule.forward (constituent_blocks.py:402-437) in eval mode, written with explicit
+    attention arithmetic (packed in_proj when kdim == vdim == C, which is the self-attention use)."""
+    z = query                                           # (N, S, C)
+    n, s, c = z.shape
+    dh = c // num_heads
+    for i in range(depth):
+        w_in, b_in = p[f"{pre}mhas.{i}.in_proj_weight"], p[f"{pre}mhas.{i}.in_proj_bias"]
+        q = F.linear(z, w_in[:c], b_in[:c])
+        k = F.linear(cond, w_in[c:2 * c], b_in[c:2 * c])
+        v = F.linear(cond, w_in[2 * c:], b_in[2 * c:])
+        sk = cond.shape[1]
+        q = q.view(n, s, num_heads, dh).transpose(1, 2)
+        k = k.view(n, sk, num_heads, dh).transpose(1, 2)
+        v = v.view(n, sk, num_heads, dh).transpose(1, 2)
+        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+        o = (att @ v).transpose(1, 2).reshape(n, s, c)
+        o = F.linear(o, p[f"{pre}mhas.{i}.out_proj.weight"], p[f"{pre}mhas.{i}.out_proj.bias"])
+        # GroupNorm(1, C) over the (C, S, 1) view == joint norm over C*S per sample (:425-428)
+        r = (o + z).transpose(1, 2).unsqueeze(-1)
+        r = F.group_norm(r, 1, p[f"{pre}mha_norms.{i}.weight"], p[f"{pre}mha_norms.{i}.bias"], eps=1e-5)
+        h = F.linear(r.squeeze(-1).transpose(1, 2), p[f"{pre}linears.{i}.weight"], p[f"{pre}linears.{i}.bias"])
+        h = act(h).transpose(1, 2).unsqueeze(-1) + r
+        h = F.group_norm(h, 1, p[f"{pre}linear_norms.{i}.weight"], p[f"{pre}linear_norms.{i}.bias"], eps=1e-5)
+        z = h.squeeze(-1).transpose(1, 2)
+    return z
+
+
+# --------------------------------------------------------------------------- loops
+def train_step_grads(p: Params, cfg: UNetCfg, s: Dict[str, Tensor], x0: Tensor, t: Tensor, noise: Tensor,
+                     masks: Optional[List[Tensor]] = None, method: str = "mse") -> Tuple[Tensor, Params]:
+    """One micro-step of BaseTrainer._forward_pass + backward (base_trainer.py:196-225):
+    q -> UNet -> ELBO -> autograd.  Returns (loss, {name: grad})."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    x_t = q_sample(s, x0, t, noise)
+    pred = unet_forward(leaves, cfg, x_t, t, drop=DropMasks(masks))
+    loss = elbo_loss(s, t, pred, x0, method)
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    return loss.detach(), dict(zip(names, grads))
+
+
+@torch.no_grad()
+def sample_chain(p: Params, cfg: UNetCfg, s: Dict[str, Tensor], x_T: Tensor, T: int,
+                 noises: Sequence[Tensor], method: str = "mse", steps: Optional[int] = None) -> Tensor:
+    """DDPM.sample's loop (ddpm.py:153-164) on a given start tensor and given per-step
+    noise; returns the tensor before the (x+1)/2 rescale.  steps limits the number of
+    iterations (default: all T)."""
+    x = x_T
+    n = x.shape[0]
+    times = torch.full((n,), T, dtype=torch.long)
+    k = 0
+    while T >= 1 and (steps is None or k < steps):
+        x0p = unet_forward(p, cfg, x, times)
+        if method == "bce":
+            x0p = torch.sigmoid(x0p)
+        x = reverse_step(s, x, x0p, times, noises[k])
+        T -= 1
+        times = times - 1
+        k += 1
+    return x
+
+
+def to_unit_range(x: Tensor) -> Tensor:
+    """(x+1)/2 then clamp to [0,1]: DDPM.sample's rescale + to_image's min/max (ddpm.py:164; utils/other_utils.py:31-34)."""
+    return ((x + 1) / 2).clamp(0.0, 1.0)
+
+
+# --------------------------------------------------------------------------- deterministic parameters
+def hash_fill(shape: Sequence[int], seed: int, scale: float, offset: float = 0.0) -> Tensor:
+    """Platform-independent pseudo-random fp32 tensor on [offset-scale, offset+scale): an integer hash
+    of the element index (oracle/noise.py).  Gives goldens reproducible weights without storing them
+    and without relying on any RNG stream."""
+    from oracle.noise import _hash_u32, _numel
+    u = _hash_u32(_numel(shape), seed).double() / 4294967296.0 - 0.5
+    return (u * (2.0 * scale) + offset).float().view(*shape)
+
+
+def param_shapes(cfg: UNetCfg, prefix: str = "model.") -> Dict[str, Tuple[int, ...]]:
+    """Every state_dict key of DDPM(BaseUNet) with its shape, in registration order
+    (unets.py:40-90,146-193; constituent_blocks.py:63-90,165-193,308-317; conv_block.py:57-116)."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    st = list(cfg.stages_channels)
+    te = cfg.t_embed_dim
+
+    def conv(name, co, ci, k):
+        out[name + "weight"] = (co, ci, k, k)
+        out[name + "bias"] = (co,)
+
+    def norm(name, c):
+        out[name + "weight"] = (c,)
+        out[name + "bias"] = (c,)
+
+    def sir(name, c):
+        e = int(cfg.expand_factor * c)
+        conv(name + "expansion.1.", e, c, 1); norm(name + "expansion.2.", e)
+        conv(name + "depthwise.1.", e, 1, 3); norm(name + "depthwise.2.", e)
+        conv(name + "projection.1.", c, e, 1); norm(name + "projection.2.", c)
+
+    def embed(name, c):
+        out[name + "layers.0.weight"] = (2 * c, te); out[name + "layers.0.bias"] = (2 * c,)
+        out[name + "layers.2.weight"] = (c, 2 * c); out[name + "layers.2.bias"] = (c,)
+
+    e = prefix + "encoder."
+    conv(e + "stem_layers.0.", st[0], cfg.img_channels, 3)
+    ins = [st[0]] + st[:-1]
+    for i, (ci, co) in enumerate(zip(ins, st)):
+        b = f"{e}layers.{i}.layers."
+        conv(b + "0.0.", co, ci, 3); norm(b + "0.1.", co)
+        sir(b + "1.", co); sir(b + "2.", co)
+        conv(b + "3.0.", co, co, 3); norm(b + "3.1.", co)
+    for i, ci in enumerate(ins):
+        embed(f"{e}t_embeddings.{i}.", ci)
+    conv(e + "latent_layers.0.", cfg.latent_dim, st[-1], 3); norm(e + "latent_layers.1.", cfg.latent_dim)
+
+    d = prefix + "decoder."
+    rs = st[::-1]
+    conv(d + "decoder_input_layers.0.", rs[0], cfg.latent_dim, 3); norm(d + "decoder_input_layers.1.", rs[0])
+    outs = rs[1:] + [rs[-1]]
+    for i, (ci, co) in enumerate(zip(rs, outs)):
+        b = f"{d}layers.{i}.layers."
+        conv(b + "0.0.", ci, 2 * ci, 3); norm(b + "0.1.", ci)
+        sir(b + "1.", ci)
+        out[b + "2.0.weight"] = (ci, co, 2, 2); out[b + "2.0.bias"] = (co,); norm(b + "2.1.", co)
+        sir(b + "3.", co); sir(b + "4.", co)
+    for i, ci in enumerate(rs):
+        embed(f"{d}t_embeddings.{i}.", ci)
+    conv(d + "out_layers.0.", rs[-1], rs[-1], 3)
+    conv(d + "out_layers.2.", cfg.img_channels, rs[-1], 3)
+    return out
+
+
+def hash_params(cfg: UNetCfg, seed: int = 1, prefix: str = "model.") -> Params:
+    """Deterministic, well-conditioned parameters for goldens: conv/linear weights ~ U(+-sqrt(3/fan_in))
+    (unit-gain), biases ~ U(+-0.2), GroupNorm gamma ~ 1 +- 0.3, beta ~ U(+-0.3)."""
+    p: Params = {}
+    for i, (k, shp) in enumerate(param_shapes(cfg, prefix).items()):
+        if len(shp) >= 2:
+            fan_in = 1
+            for dd in shp[1:]:
+                fan_in *= dd
+            if ".layers.2.0.weight" in k and len(shp) == 4 and shp[2] == 2:   # ConvTranspose2d (in,out,2,2)
+                fan_in = shp[0]
+            p[k] = hash_fill(shp, seed * 1000 + i, math.sqrt(3.0 / fan_in))
+        elif k.endswith("weight"):
+            p[k] = hash_fill(shp, seed * 1000 + i, 0.3, 1.0)
+        else:
+            norm_bias = any(t in k for t in (".0.1.bias", ".3.1.bias", ".2.1.bias", "expansion.2.bias", "depthwise.2.bias",
+                                              "projection.2.bias", "latent_layers.1.bias", "decoder_input_layers.1.bias"))
+            p[k] = hash_fill(shp, seed * 1000 + i, 0.3 if norm_bias else 0.2)
+    return p

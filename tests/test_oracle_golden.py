@@ -1,0 +1,153 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) to fixtures produced by the reference itself
+(tools/gen_golden.py).  CPU only; tolerances are fp32 round-off of re-associated sums."""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from oracle.noise import hash_normal, hash_uniform
+
+RT, AT = 2e-5, 2e-6
+
+
+def close(a, b, rtol=RT, atol=AT):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+def test_schedule_tables_bit_exact(golden):
+    g = golden("schedule_T120_b025.pt")
+    s = O.make_schedule(g["T"], g["beta"])
+    for k, v in g["tables"].items():
+        assert s[k].shape == v.shape == (121, 1, 1, 1)
+        assert torch.equal(torch.nan_to_num(s[k], nan=-7.0), torch.nan_to_num(v, nan=-7.0)), k
+    # index-0 singularities of the reference tables (beta_0 = 0)
+    assert math.isinf(s["x_previous_coef"][0].item()) and math.isnan(s["x0_pred_coef"][0].item())
+
+
+def test_q_reverse_elbo(golden):
+    g = golden("diffusion_ops.pt")
+    s = O.make_schedule(120, 0.25)
+    assert torch.equal(O.q_sample(s, g["x0"], g["t"], g["eps"]), g["x_t"])
+    assert torch.equal(O.reverse_step(s, g["x_t"], g["x0_pred"], g["t"], g["z"]), g["x_prev"])
+    # t = 1 returns the prediction itself (up to fp32 rounding of beta_1/(1-abar_1)), no noise
+    close(g["x_prev"][0], g["x0_pred"][0], 5e-5, 5e-5)
+    xp = g["x0_pred"].clone().requires_grad_(True)
+    loss = O.elbo_loss(s, g["t"], xp, g["x0"], "mse")
+    close(loss, g["loss_mse"])
+    close(torch.autograd.grad(loss, xp)[0], g["grad_mse"])
+    close(O.elbo_loss(s, g["t"], g["x0_pred"], (g["x0"] + 1) / 2, "bce"), g["loss_bce"])
+    close(O.elbo_loss(s, g["t"], g["x0_pred"], g["x0"], "mse", use_elbo=False), g["loss_plain"])
+    close(g["loss_mse_ddpflag"], g["loss_mse"])
+
+
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+def test_blocks(golden, act):
+    g = golden("blocks.pt")
+    a = O.act_fn(act)
+
+    def run(fn, rec, inputs):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in rec["params"].items()}
+        xs = [rec[k].clone().requires_grad_(True) for k in inputs]
+        y = fn(leaves, *xs)
+        close(y, rec["y"], 1e-4, 1e-5)
+        grads = torch.autograd.grad(y, xs + list(leaves.values()), rec["gy"])
+        for k, gx in zip(inputs, grads):
+            close(gx, rec["g" + k], 1e-4, 1e-4)
+        for k, gp in zip(leaves, grads[len(xs):]):
+            close(gp, rec["gparams"][k], 1e-4, 2e-4)
+
+    run(lambda p, x: O.sir_block(p, "", x, 16, a, O.DropMasks()), g[f"sir.{act}"], ["x"])
+    run(lambda p, x: O.down_block(p, "", x, 16, a, O.DropMasks()), g[f"down.{act}"], ["x"])
+    run(lambda p, x, skip: O.up_block(p, "", x, skip, 16, a, O.DropMasks()), g[f"up.{act}"], ["x", "skip"])
+    e = g[f"embed.{act}"]
+    sin = O.sinusoidal(e["t"].float() / 100, 32)
+    close(sin, e["sin"])
+    close(O.embed_block(e["params"], "", sin, a), e["y"])
+
+
+def _digest_close(g, d, rtol):
+    flat = g.reshape(-1).double()
+    l2 = flat.norm().item()
+    assert abs(l2 - d["l2"]) <= rtol * max(d["l2"], 1e-6), (l2, d["l2"])
+    ref = d["val"].double()
+    got = flat[d["idx"]]
+    assert (got - ref).abs().max().item() <= rtol * max(d["l2"] / math.sqrt(flat.numel()), 1e-7) * 10 + rtol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("tag,c,act", [("c3.gelu", 3, "gelu"), ("c1.gelu", 1, "gelu"), ("c3.silu", 3, "silu")])
+def test_unet_full_forward_backward(golden, tag, c, act):
+    g = golden("unet_full.pt")[tag]
+    cfg = O.UNetCfg(img_channels=c, activation=act, drop_p=0.0)
+    p = O.hash_params(cfg, seed=1)
+    assert sum(v.numel() for v in p.values()) == g["n_params"] == (6857763 if c == 3 else 6856609)
+    assert len(p) == 350
+    s = O.make_schedule(120, 0.25)
+    x_t = O.q_sample(s, g["x0"], g["t"], hash_normal(tuple(g["x0"].shape), 401))
+    assert torch.equal(x_t, g["x_t"])
+    taps = {}
+    with torch.no_grad():
+        pred = O.unet_forward(p, cfg, x_t, g["t"], taps=taps)
+    for k, v in g["taps"].items():
+        close(taps[k], v, 2e-4, 2e-5)
+    close(pred, g["pred"], 2e-4, 2e-5)
+    loss, grads = O.train_step_grads(p, cfg, s, g["x0"], g["t"], hash_normal(tuple(g["x0"].shape), 401))
+    close(loss, g["loss"], 1e-4, 1e-7)
+    for k, d in g["grad_digest"].items():
+        _digest_close(grads[k], d, 2e-3)
+
+
+def test_unet_dropout_sites(golden):
+    g = golden("unet_full.pt")["c3.gelu.dropout"]
+    cfg = O.UNetCfg(img_channels=3, activation="gelu", drop_p=0.1)
+    assert g["sites"] == O.count_dropout_sites(cfg) == 60
+    p = O.hash_params(cfg, seed=1)
+    s = O.make_schedule(120, 0.25)
+    x_t = O.q_sample(s, g["x0"], g["t"], hash_normal(tuple(g["x0"].shape), 401))
+    shapes = []
+
+    class Rec(O.DropMasks):
+        def __call__(self, v):
+            shapes.append(tuple(v.shape))
+            return v
+
+    with torch.no_grad():
+        O.unet_forward(p, cfg, x_t, g["t"], drop=Rec())
+    masks = [(hash_uniform(sh, 9000 + i) < 0.9).float() / 0.9 for i, sh in enumerate(shapes)]
+    with torch.no_grad():
+        pred = O.unet_forward(p, cfg, x_t, g["t"], drop=O.DropMasks(masks))
+    close(pred, g["pred"], 2e-4, 2e-5)
+    loss, grads = O.train_step_grads(p, cfg, s, g["x0"], g["t"], hash_normal(tuple(g["x0"].shape), 401), masks=masks)
+    close(loss, g["loss"], 1e-4, 1e-7)
+    for k in list(g["grad_digest"])[::25]:
+        _digest_close(grads[k], g["grad_digest"][k], 2e-3)
+
+
+def test_sample_chain(golden):
+    g = golden("sample_chain.pt")
+    cfg = O.UNetCfg(img_channels=3, activation="gelu", drop_p=0.0)
+    p = O.hash_params(cfg, seed=1)
+    s = O.make_schedule(120, 0.25)
+    shp = (g["N"], 3) + tuple(g["shape"])
+    base = g["noise_seed_base"]
+    x_T = hash_normal(shp, base + 1)
+    noises = [hash_normal(shp, base + 2 + k) for k in range(120)]
+    for k in (1, 2):
+        close(O.sample_chain(p, cfg, s, x_T, 120, noises, steps=k), g["snapshots"][k], 2e-4, 2e-5)
+    final = O.sample_chain(p, cfg, s, x_T, 120, noises)
+    close(final, g["snapshots"][120], 1e-3, 1e-4)
+    close(O.to_unit_range(final), g["final_unit"], 1e-3, 1e-4)
+
+
+def test_conditional_module(golden):
+    g = golden("conditional_module.pt")
+    p = {}
+    for i, (k, shp) in enumerate(g["shapes"].items()):
+        if len(shp) >= 2:
+            p[k] = O.hash_fill(shp, g["param_seed_base"] + i, (3.0 / shp[-1]) ** 0.5)
+        elif "norm" in k and k.endswith("weight"):
+            p[k] = O.hash_fill(shp, g["param_seed_base"] + i, 0.2, 1.0)
+        else:
+            p[k] = O.hash_fill(shp, g["param_seed_base"] + i, 0.1)
+    y = O.conditional_module(p, "", g["q"], g["q"], g["depth"], O.act_fn("gelu"), g["heads"])
+    close(y, g["y_self"], 2e-4, 2e-5)
