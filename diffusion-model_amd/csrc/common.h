@@ -1,0 +1,126 @@
+// Shared device/host helpers for the gfx950 DDPM kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define DDPM_OK 0
+#define DDPM_EINVAL (-1)
+#define DDPM_EHIP (-2)
+
+// Activation codes shared by every kernel and by the host side.
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
+
+void ddpm_set_error(const char* fmt, ...);
+int ddpm_check_launch(const char* what);
+
+#define DDPM_REQUIRE(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            ddpm_set_error(__VA_ARGS__);         \
+            return DDPM_EINVAL;                  \
+        }                                        \
+    } while (0)
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));
+        case ACT_SILU: return z / (1.0f + __expf(-z));
+        case ACT_RELU: return z > 0.f ? z : 0.f;
+        case ACT_TANH: return tanhf(z);
+        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-z));
+        default: return z;
+    }
+}
+
+// d act(z) / dz
+__device__ __forceinline__ float act_bwd(float z, int act) {
+    switch (act) {
+        case ACT_GELU: {
+            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+            const float pdf = 0.39894228040143268f * __expf(-0.5f * z * z);
+            return cdf + z * pdf;
+        }
+        case ACT_SILU: {
+            const float s = 1.0f / (1.0f + __expf(-z));
+            return s * (1.0f + z * (1.0f - s));
+        }
+        case ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case ACT_TANH: {
+            const float t = tanhf(z);
+            return 1.0f - t * t;
+        }
+        case ACT_SIGMOID: {
+            const float s = 1.0f / (1.0f + __expf(-z));
+            return s * (1.0f - s);
+        }
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (counter-based RNG)
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+// Keep-mask bits for the 8 consecutive elements whose first flat index is 8*vec_index, at a dropout
+// site.  Bit j set => element j kept.  thresh = keep_prob * 65536.  Depends only on (seed, site, vec_index),
+// so the forward, data-gradient and weight-gradient kernels regenerate identical masks.
+__device__ __forceinline__ uint32_t dropout_keep8(uint64_t seed, uint32_t site, uint64_t vec_index, uint32_t thresh) {
+    const Philox4 r = philox4x32_10((uint32_t)vec_index, (uint32_t)(vec_index >> 32), site, 0x0d0b0a17u,
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t m = 0;
+    m |= ((r.x & 0xFFFFu) < thresh) << 0;
+    m |= ((r.x >> 16) < thresh) << 1;
+    m |= ((r.y & 0xFFFFu) < thresh) << 2;
+    m |= ((r.y >> 16) < thresh) << 3;
+    m |= ((r.z & 0xFFFFu) < thresh) << 4;
+    m |= ((r.z >> 16) < thresh) << 5;
+    m |= ((r.w & 0xFFFFu) < thresh) << 6;
+    m |= ((r.w >> 16) < thresh) << 7;
+    return m;
+}
+
+// Four N(0,1) samples for flat element indices 4*q .. 4*q+3 of stream `stream_id`.
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t stream_id, uint64_t q) {
+    const Philox4 r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream_id, 0x6a09e667u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u0 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+    const float u1 = (float)r.y * 2.3283064365386963e-10f;
+    const float u2 = ((float)r.z + 1.0f) * 2.3283064365386963e-10f;
+    const float u3 = (float)r.w * 2.3283064365386963e-10f;
+    const float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u1, &s0, &c0);
+    __sincosf(6.283185307179586f * u3, &s1, &c1);
+    f32x4 o;
+    o[0] = ra * c0; o[1] = ra * s0; o[2] = rb * c1; o[3] = rb * s1;
+    return o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

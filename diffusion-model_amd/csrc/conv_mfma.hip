@@ -1,0 +1,261 @@
+// Implicit-GEMM convolution on bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for gfx950.
+//
+// One kernel serves the forward pass AND the data-gradient of every dense convolution in the UNet
+// (3x3 stride 1/2, 1x1 / Linear, transposed 2x2 stride 2); see conv_geom.h for the tap-list form.
+//
+//   GEMM view per class:  M = positions (N*GH*GW),  N = output channels,  K = taps x input channels.
+//   A operand  = input patch rows (one pixel = one row of 32 channels) read from LDS at pixel + tap offset
+//   B operand  = weight rows [out channel][32 in channels] of the tap's slice, read from LDS
+//   Wave tile  = 32 positions x (32*NT) output channels; workgroup = WAVES waves stacked along M.
+//
+// Per 32-channel chunk the patch (with halo) is loaded from HBM exactly once, through registers, which is
+// where the fused input transforms happen: two-source channel concat (decoder skip connection), the
+// per-(n, c) time-embedding broadcast add, and the input dropout mask.  Epilogue: bias, activation,
+// dropout mask, residual add, staged through LDS so that global stores are 16-byte NHWC vectors.
+#include "conv_geom.h"
+#include "ddpm_hip.h"
+
+struct ConvArgs {
+    ConvGeom g;
+    const bf16* in0; const bf16* in1; int C0, C1;
+    const float* in_add;             // [N][C0] fp32, added to in-bounds pixels of source 0 (nullable)
+    const unsigned char* in_mask;    // keep bits for source 0, one byte per 8 consecutive elements (nullable)
+    float in_mask_scale;
+    const bf16* w; const float* bias;
+    void* out; const bf16* res; const unsigned char* out_mask; float out_mask_scale;
+    int Cout, CoutW, out_cs;         // real output channels; rows per weight slice; channel stride of out
+    int act, out_mode;
+};
+
+template <int WAVES, int NT>
+__global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int T = 64 * WAVES, BM = 32 * WAVES, BN = 32 * NT;
+    constexpr int OS = BN * 2 + 16;   // epilogue LDS row stride (bytes)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cls = blockIdx.z;
+    const int tap0 = g.cls_tap_begin[cls], ntaps = g.cls_tap_begin[cls + 1] - tap0;
+    const int co0 = blockIdx.y * BN;
+    int tile = blockIdx.x;
+    const int twi = tile % g.tiles_w; tile /= g.tiles_w;
+    const int thi = tile % g.tiles_h;
+    const int tni = tile / g.tiles_h;
+    const int n0 = tni * g.NB, oy = thi * g.TH, ox = twi * g.TW;
+    const int PHW = g.PH * g.PW, npix = g.NB * PHW;
+    const int Cin = a.C0 + a.C1;
+
+    int* s_pl = (int*)smem;                                      // pixel linear index (or -1) per patch pixel
+    char* s_patch = smem + ((npix * 4 + 15) & ~15);
+    char* s_w = s_patch + npix * CONV_RS;
+
+    // ---- patch pixel table: patch slot -> linear input pixel (n*IH + iy)*IW + ix, or -1 if padding
+    for (int p = tid; p < npix; p += T) {
+        const int il = p / PHW, r = p - il * PHW;
+        const int py = r / g.PW, px = r - py * g.PW;
+        const int n = n0 + il, iy = oy * g.SI + g.dmin_h + py, ix = ox * g.SI + g.dmin_w + px;
+        const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+        s_pl[p] = ok ? (n * g.IH + iy) * g.IW + ix : -1;
+    }
+
+    // ---- this lane's A row (position) -> byte offset of its pixel inside the patch
+    const int thw = g.TH * g.TW;
+    const int pidx = wave * 32 + (lane & 31);
+    const int il = pidx / thw, rem = pidx - il * thw;
+    const int ty = rem / g.TW, tx = rem - ty * g.TW;
+    const int a_base = (il * PHW + ty * g.SI * g.PW + tx * g.SI) * CONV_RS + (lane >> 5) * 16;
+    const int b_base = (lane & 31) * CONV_RS + (lane >> 5) * 16;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int ihw = g.IH * g.IW;
+    for (int c0 = 0; c0 < Cin; c0 += CONV_CK) {
+        const int parts = (Cin - c0 >= CONV_CK) ? 4 : (Cin - c0) / 8;   // 16-byte pieces per row in this chunk
+        const int ksteps = (parts + 1) / 2;
+        __syncthreads();   // previous chunk fully consumed (and s_pl visible on the first trip)
+        // -- stage patch
+        const bool src1 = c0 >= a.C0;
+        const bf16* src = src1 ? a.in1 : a.in0;
+        const int cs = src1 ? a.C1 : a.C0, cc = src1 ? c0 - a.C0 : c0;
+        for (int it = tid; it < npix * 4; it += T) {
+            const int p = it >> 2, part = it & 3;
+            if (part >= parts) continue;
+            const int pl = s_pl[p];
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+            if (pl >= 0) {
+                const long long e = (long long)pl * cs + cc + part * 8;
+                v = *(const bf16x8*)(src + e);
+                if (!src1) {
+                    if (a.in_add) {
+                        const float* ad = a.in_add + (pl / ihw) * a.C0 + cc + part * 8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + ad[j]);
+                    }
+                    if (a.in_mask) {
+                        const unsigned m = a.in_mask[e >> 3];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.in_mask_scale) : (bf16)0.f;
+                    }
+                }
+            }
+            *(bf16x8*)(s_patch + p * CONV_RS + part * 16) = v;
+        }
+        // -- stage weights: rows = (tap, out channel), 32 input channels each
+        for (int it = tid; it < ntaps * BN * 4; it += T) {
+            const int row = it >> 2, part = it & 3;
+            if (part >= parts) continue;
+            const int j = row / BN, co = row - j * BN;
+            const bf16* wp = a.w + ((long long)g.tap_slice[tap0 + j] * a.CoutW + co0 + co) * Cin + c0 + part * 8;
+            *(bf16x8*)(s_w + row * CONV_RS + part * 16) = *(const bf16x8*)wp;
+        }
+        __syncthreads();
+        // -- MFMA over taps x k-steps
+        for (int j = 0; j < ntaps; ++j) {
+            const char* ap = s_patch + a_base + g.tap_poff[tap0 + j] * CONV_RS;
+            const char* bp = s_w + j * BN * CONV_RS + b_base;
+            for (int kk = 0; kk < ksteps; ++kk) {
+                const bf16x8 av = *(const bf16x8*)(ap + kk * 32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 bv = *(const bf16x8*)(bp + nt * 32 * CONV_RS + kk * 32);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    const int offh = g.cls_off_h[cls], offw = g.cls_off_w[cls];
+    if (a.out_mode == OUT_F32_NCHW) {
+        // few output channels (the image head): scattered fp32 stores straight from the accumulators
+        float* out = (float*)a.out;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = co0 + nt * 32 + (lane & 31);
+            if (co >= a.Cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ril = row / thw, rr = row - ril * thw;
+                const int rty = rr / g.TW, rtx = rr - rty * g.TW;
+                const int n = n0 + ril, py = oy + rty, px = ox + rtx;
+                const int oh = py * g.SO + offh, ow = px * g.SO + offw;
+                if (n < g.N && py < g.GH && px < g.GW && oh < g.OH && ow < g.OW)
+                    out[(((long long)n * a.Cout + co) * g.OH + oh) * g.OW + ow] = act_fwd(acc[nt][r] + b, a.act);
+            }
+        }
+        return;
+    }
+    __syncthreads();   // every wave is done reading the operand tiles; reuse LDS for the output tile
+    char* s_out = smem;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 32 + (lane & 31);
+        const float b = (a.bias && co0 + col < a.Cout) ? a.bias[co0 + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            *(bf16*)(s_out + row * OS + col * 2) = (bf16)act_fwd(acc[nt][r] + b, a.act);
+        }
+    }
+    __syncthreads();
+    bf16* out = (bf16*)a.out;
+    for (int it = tid; it < BM * (BN / 8); it += T) {
+        const int row = it / (BN / 8), part = it - row * (BN / 8);
+        const int co = co0 + part * 8;
+        if (co >= a.Cout) continue;
+        const int ril = row / thw, rr = row - ril * thw;
+        const int rty = rr / g.TW, rtx = rr - rty * g.TW;
+        const int n = n0 + ril, py = oy + rty, px = ox + rtx;
+        const int oh = py * g.SO + offh, ow = px * g.SO + offw;
+        if (!(n < g.N && py < g.GH && px < g.GW && oh < g.OH && ow < g.OW)) continue;
+        const long long e = ((long long)(n * g.OH + oh) * g.OW + ow) * a.out_cs + co;
+        bf16x8 v = *(const bf16x8*)(s_out + row * OS + part * 16);
+        if (a.out_mask) {
+            const unsigned m = a.out_mask[e >> 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.out_mask_scale) : (bf16)0.f;
+        }
+        if (a.res) {
+            const bf16x8 rv = *(const bf16x8*)(a.res + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)rv[j]);
+        }
+        if (co + 8 <= a.Cout) {
+            *(bf16x8*)(out + e) = v;
+        } else {
+            for (int j = 0; j < a.Cout - co; ++j) out[e + j] = v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <int WAVES, int NT>
+static int launch_conv(const ConvArgs& a, size_t lds, hipStream_t stream) {
+    const ConvGeom& g = a.g;
+    auto k = conv_mfma_kernel<WAVES, NT>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ddpm_check_launch("conv: raise dynamic LDS limit");
+    }
+    dim3 grid(g.tiles_n * g.tiles_h * g.tiles_w, a.CoutW / (32 * NT), g.ncls);
+    hipLaunchKernelGGL(k, grid, dim3(64 * WAVES), lds, stream, a);
+    return ddpm_check_launch("conv_mfma");
+}
+
+extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(d && d->in0 && d->w && d->out, "conv: null pointer");
+    DDPM_REQUIRE(d->kind >= 0 && d->kind < CONV_KIND_COUNT, "conv: unknown kind %d", d->kind);
+    DDPM_REQUIRE(d->N > 0 && d->IH > 0 && d->IW > 0, "conv: bad input dims %d x %d x %d", d->N, d->IH, d->IW);
+    DDPM_REQUIRE(d->C0 > 0 && d->C0 % 16 == 0 && d->C1 >= 0 && d->C1 % 32 == 0 && (d->C1 == 0 || (d->in1 && d->C0 % 32 == 0)),
+                 "conv: input channels must be multiples of 16 (32 when two sources are concatenated); got %d + %d", d->C0, d->C1);
+    DDPM_REQUIRE(d->Cout > 0 && d->CoutW >= d->Cout && d->CoutW % 32 == 0, "conv: CoutW (%d) must be a multiple of 32 >= Cout (%d)",
+                 d->CoutW, d->Cout);
+    DDPM_REQUIRE(d->out_mode == OUT_F32_NCHW || (d->out_cs >= d->Cout && d->out_cs % 8 == 0),
+                 "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
+    DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
+    DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
+
+    ConvArgs a;
+    const long long positions_guess = (long long)d->N * d->IH * d->IW;
+    // tile height along M: 128 positions normally, 64 when the whole layer would otherwise fill < 1/2 of the CUs
+    int nt = d->CoutW / 32;
+    const int kind_taps = (d->kind == CONV_3X3_S1 || d->kind == CONV_3X3_S2) ? 9 : 4;
+    const int nt_cap = kind_taps >= 9 ? 2 : 4;
+    if (nt > nt_cap) nt = nt_cap;
+    if (nt == 3) nt = 2;
+    while ((d->CoutW / 32) % nt) --nt;
+    int waves = 4;
+    if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 128) != 0) { ddpm_set_error("conv: geometry"); return DDPM_EINVAL; }
+    {
+        const long long blocks = (long long)a.g.tiles_n * a.g.tiles_h * a.g.tiles_w * (d->CoutW / (32 * nt)) * a.g.ncls;
+        if (blocks < 192 && positions_guess >= 64) waves = 2;
+    }
+    if (waves == 2) conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 64);
+    a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1;
+    a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
+    a.w = (const bf16*)d->w; a.bias = d->bias; a.out = d->out; a.res = (const bf16*)d->res;
+    a.out_mask = d->out_mask; a.out_mask_scale = d->out_mask_scale;
+    a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.act = d->act; a.out_mode = d->out_mode;
+
+    const int npix = a.g.NB * a.g.PH * a.g.PW;
+    const int bm = 32 * waves, bn = 32 * nt;
+    size_t lds = ((size_t)npix * 4 + 15) / 16 * 16 + (size_t)npix * CONV_RS + (size_t)a.g.max_taps * bn * CONV_RS;
+    const size_t lds_out = (size_t)bm * (bn * 2 + 16);
+    if (lds < lds_out) lds = lds_out;
+    DDPM_REQUIRE(lds <= 160 * 1024, "conv: tile needs %zu B of LDS", lds);
+
+#define CONV_CASE(W, NTv) if (waves == W && nt == NTv) return launch_conv<W, NTv>(a, lds, stream);
+    CONV_CASE(4, 1) CONV_CASE(4, 2) CONV_CASE(4, 4) CONV_CASE(2, 1) CONV_CASE(2, 2) CONV_CASE(2, 4)
+#undef CONV_CASE
+    ddpm_set_error("conv: no kernel for waves=%d nt=%d", waves, nt);
+    return DDPM_EINVAL;
+}

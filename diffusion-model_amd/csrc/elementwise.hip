@@ -1,0 +1,309 @@
+// Fused elementwise kernels of the diffusion process: forward noising (q), ancestral reverse step,
+// ELBO-weighted loss forward/backward, time embedding, and the NCHW<->NHWC layout/precision bridges
+// at the UNet boundary.  All of them are HBM-streaming kernels: 16-byte vector accesses, grid capped
+// at a few blocks per CU with a grid-stride loop.
+#include "common.h"
+#include "ddpm_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing shared by the whole library
+static thread_local char g_err[512] = "";
+
+void ddpm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ddpm_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ddpm_set_error("%s: %s", what, hipGetErrorString(e));
+        return DDPM_EHIP;
+    }
+    return DDPM_OK;
+}
+
+extern "C" const char* ddpm_last_error(void) { return g_err; }
+extern "C" int ddpm_abi_version(void) { return 1; }
+
+static inline int stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+// Per-timestep scalars, one row of 8 floats per t (row 0 is unused: t runs 1..T).
+enum { SC_SQRT_AB = 0, SC_SQRT_1MAB = 1, SC_A = 2, SC_B = 3, SC_C = 4, SC_W = 5, SC_STRIDE = 8 };
+
+// ------------------------------------------------------------------------------------------------
+// q: x_t = sqrt(abar_t) * x0 + sqrt(1 - abar_t) * eps       (reference ddpm.py:102-106)
+// Reads x0 (NCHW fp32) and eps (external tensor, or Philox N(0,1) generated in-kernel), writes x_t as
+// NCHW fp32 and/or as the channel-padded NHWC bf16 tensor the stem convolution consumes.
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const long long* __restrict__ t,
+                                                        const float* __restrict__ noise, const float* __restrict__ sched,
+                                                        float* __restrict__ xt, bf16* __restrict__ xt_nhwc, int cpad, int N, int C,
+                                                        int HW, const unsigned long long* __restrict__ seed, unsigned stream_id) {
+    const long long chw = (long long)C * HW;
+    const long long total4 = (long long)N * chw / 4;
+    const unsigned long long sd = seed ? *seed : 0ull;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total4; q += (long long)gridDim.x * blockDim.x) {
+        const long long e = q * 4;
+        const int n = (int)(e / chw);
+        const int ti = (int)t[n];
+        const float a = sched[ti * SC_STRIDE + SC_SQRT_AB], b = sched[ti * SC_STRIDE + SC_SQRT_1MAB];
+        const f32x4 x = *(const f32x4*)(x0 + e);
+        const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, stream_id, (unsigned long long)q);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(a, x[j]), __fmul_rn(b, z[j]));
+        if (xt) *(f32x4*)(xt + e) = o;
+        if (xt_nhwc) {
+            const long long r = e - (long long)n * chw;
+            const int c = (int)(r / HW);
+            const int p = (int)(r - (long long)c * HW);  // HW % 4 == 0, so the four elements share n and c
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xt_nhwc[((long long)n * HW + p + j) * cpad + c] = (bf16)o[j];
+        }
+    }
+}
+
+extern "C" int ddpm_q_sample(const float* x0, const int64_t* t_, const float* noise, const float* sched, float* xt, void* xt_nhwc,
+                             int cpad, int N, int C, int HW, const uint64_t* seed_, uint32_t stream_id, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long* t = (const long long*)t_;
+    const unsigned long long* seed = (const unsigned long long*)seed_;
+    DDPM_REQUIRE(x0 && t && sched && (xt || xt_nhwc), "q_sample: null pointer");
+    DDPM_REQUIRE(noise || seed, "q_sample: need an external noise tensor or a device seed");
+    DDPM_REQUIRE(N > 0 && C > 0 && HW > 0 && HW % 4 == 0, "q_sample: H*W must be a positive multiple of 4 (got %d)", HW);
+    DDPM_REQUIRE(!xt_nhwc || cpad >= C, "q_sample: cpad %d < C %d", cpad, C);
+    if (xt_nhwc && cpad > C) {
+        if (hipMemsetAsync(xt_nhwc, 0, (size_t)N * HW * cpad * sizeof(bf16), stream) != hipSuccess) return ddpm_check_launch("q_sample memset");
+    }
+    const long long total4 = (long long)N * C * HW / 4;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, stream, x0, t, noise, sched, xt, (bf16*)xt_nhwc,
+                       cpad, N, C, HW, seed, stream_id);
+    return ddpm_check_launch("q_sample");
+}
+
+// ------------------------------------------------------------------------------------------------
+// reverse step: x_{t-1} = A_t x_t + B_t x0_pred + C_t z        (reference ddpm.py:138-144)
+// A_t = (1-abar_{t-1}) sqrt(alpha_t)/(1-abar_t), B_t = sqrt(abar_{t-1}) beta_t/(1-abar_t),
+// C_t = sqrt(1-abar_{t-1}) sqrt(beta_t/(1-abar_t)); C_1 = 0 so the last step adds no noise.
+__global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restrict__ xt, const float* __restrict__ x0p,
+                                                            const long long* __restrict__ t, const float* __restrict__ noise,
+                                                            const float* __restrict__ sched, float* __restrict__ out, int N, long long chw,
+                                                            const unsigned long long* __restrict__ seed, unsigned stream_id,
+                                                            int sigmoid_pred) {
+    const long long total4 = (long long)N * chw / 4;
+    const unsigned long long sd = seed ? *seed : 0ull;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total4; q += (long long)gridDim.x * blockDim.x) {
+        const long long e = q * 4;
+        const int n = (int)(e / chw);
+        const int ti = (int)t[n];
+        const float A = sched[ti * SC_STRIDE + SC_A], B = sched[ti * SC_STRIDE + SC_B], Cc = sched[ti * SC_STRIDE + SC_C];
+        const f32x4 x = *(const f32x4*)(xt + e);
+        f32x4 p = *(const f32x4*)(x0p + e);
+        const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, stream_id, (unsigned long long)q);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (sigmoid_pred) p[j] = 1.0f / (1.0f + __expf(-p[j]));
+            o[j] = __fadd_rn(__fadd_rn(__fmul_rn(A, x[j]), __fmul_rn(B, p[j])), __fmul_rn(Cc, z[j]));
+        }
+        *(f32x4*)(out + e) = o;
+    }
+}
+
+extern "C" int ddpm_reverse_step(const float* xt, const float* x0_pred, const int64_t* t_, const float* noise, const float* sched,
+                                 float* out, int N, int64_t chw, const uint64_t* seed_, uint32_t stream_id, int sigmoid_pred,
+                                 ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long* t = (const long long*)t_;
+    const unsigned long long* seed = (const unsigned long long*)seed_;
+    DDPM_REQUIRE(xt && x0_pred && t && sched && out, "reverse_step: null pointer");
+    DDPM_REQUIRE(noise || seed, "reverse_step: need an external noise tensor or a device seed");
+    DDPM_REQUIRE(N > 0 && chw > 0 && chw % 4 == 0, "reverse_step: C*H*W must be a positive multiple of 4 (got %lld)", chw);
+    hipLaunchKernelGGL(reverse_step_kernel, dim3(stream_grid((long long)N * chw / 4, 256)), dim3(256), 0, stream, xt, x0_pred, t, noise,
+                       sched, out, N, chw, seed, stream_id, sigmoid_pred);
+    return ddpm_check_launch("reverse_step");
+}
+
+// ------------------------------------------------------------------------------------------------
+// ELBO: loss = mean_{n,c,h,w}( w_t[n] * l(pred, target) ), l = squared error or BCE-with-logits
+// (reference losses/ELBO.py:61-76).  Forward reduces into one fp32 scalar (per-block partial sums
+// combined with one atomic per block); backward writes dL/dpred scaled by an upstream scalar.
+__device__ __forceinline__ float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const long long* __restrict__ t, const float* __restrict__ sched,
+                                                        float* __restrict__ loss, int N, long long chw, int bce, int weighted) {
+    __shared__ float part[4];
+    const long long total4 = (long long)N * chw / 4;
+    float acc = 0.f;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total4; q += (long long)gridDim.x * blockDim.x) {
+        const long long e = q * 4;
+        const int n = (int)(e / chw);
+        const float w = weighted ? sched[(int)t[n] * SC_STRIDE + SC_W] : 1.0f;
+        const f32x4 p = *(const f32x4*)(pred + e), y = *(const f32x4*)(target + e);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = p[j] - y[j];
+            s += bce ? bce_logits(p[j], y[j]) : d * d;
+        }
+        acc += w * s;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (float)((double)N * (double)chw));
+}
+
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const long long* __restrict__ t, const float* __restrict__ sched,
+                                                        const float* __restrict__ gscale, float* __restrict__ gpred, int N,
+                                                        long long chw, int bce, int weighted) {
+    const long long total4 = (long long)N * chw / 4;
+    const float up = (gscale ? *gscale : 1.0f) / (float)((double)N * (double)chw);
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total4; q += (long long)gridDim.x * blockDim.x) {
+        const long long e = q * 4;
+        const int n = (int)(e / chw);
+        const float w = (weighted ? sched[(int)t[n] * SC_STRIDE + SC_W] : 1.0f) * up;
+        const f32x4 p = *(const f32x4*)(pred + e), y = *(const f32x4*)(target + e);
+        f32x4 g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = w * (bce ? (1.0f / (1.0f + __expf(-p[j])) - y[j]) : 2.0f * (p[j] - y[j]));
+        *(f32x4*)(gpred + e) = g;
+    }
+}
+
+extern "C" int ddpm_elbo_fwd(const float* pred, const float* target, const int64_t* t_, const float* sched, float* loss, int N,
+                             int64_t chw, int bce, int weighted, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long* t = (const long long*)t_;
+    DDPM_REQUIRE(pred && target && t && sched && loss, "elbo_fwd: null pointer");
+    DDPM_REQUIRE(N > 0 && chw > 0 && chw % 4 == 0, "elbo_fwd: C*H*W must be a positive multiple of 4 (got %lld)", chw);
+    if (hipMemsetAsync(loss, 0, sizeof(float), stream) != hipSuccess) return ddpm_check_launch("elbo_fwd memset");
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(stream_grid((long long)N * chw / 4, 256)), dim3(256), 0, stream, pred, target, t, sched, loss,
+                       N, chw, bce, weighted);
+    return ddpm_check_launch("elbo_fwd");
+}
+
+extern "C" int ddpm_elbo_bwd(const float* pred, const float* target, const int64_t* t_, const float* sched, const float* gscale,
+                             float* gpred, int N, int64_t chw, int bce, int weighted, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long* t = (const long long*)t_;
+    DDPM_REQUIRE(pred && target && t && sched && gpred, "elbo_bwd: null pointer");
+    DDPM_REQUIRE(N > 0 && chw > 0 && chw % 4 == 0, "elbo_bwd: C*H*W must be a positive multiple of 4 (got %lld)", chw);
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(stream_grid((long long)N * chw / 4, 256)), dim3(256), 0, stream, pred, target, t, sched,
+                       gscale, gpred, N, chw, bce, weighted);
+    return ddpm_check_launch("elbo_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sinusoidal time embedding (reference constituent_blocks.py:261-279; time normalised as in
+// unets.py:121): out[n] = [sin(t/Tn * f_i), cos(t/Tn * f_i)], f_i = exp(-i ln(1e4)/(half-1)).
+__global__ void time_embedding_kernel(const long long* __restrict__ t, float inv_norm, int dim, bf16* __restrict__ out, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= N * half) return;
+    const int n = i / half, k = i - n * half;
+    const float pre = 9.210340371976184f / (float)(half - 1);
+    const float f = expf(-pre * (float)k);
+    const float a = ((float)t[n] * inv_norm) * f;
+    out[n * dim + k] = (bf16)sinf(a);
+    out[n * dim + half + k] = (bf16)cosf(a);
+}
+
+extern "C" int ddpm_time_embedding(const int64_t* t_, float time_norm, int dim, void* out, int N, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long* t = (const long long*)t_;
+    DDPM_REQUIRE(t && out && N > 0 && dim >= 4 && dim % 2 == 0, "time_embedding: bad arguments");
+    const int total = N * (dim / 2);
+    hipLaunchKernelGGL(time_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, 1.0f / time_norm, dim, (bf16*)out, N);
+    return ddpm_check_launch("time_embedding");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout bridges.  The UNet works on NHWC bf16 internally; the module boundary is NCHW fp32.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16* __restrict__ out, int N, int C, int HW,
+                                                            int cpad) {
+    const long long total = (long long)N * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW);
+        const int p = (int)(i - (long long)n * HW);
+        for (int c = 0; c < cpad; ++c) out[i * cpad + c] = c < C ? (bf16)x[((long long)n * C + c) * HW + p] : (bf16)0.f;
+    }
+}
+
+extern "C" int ddpm_nchw_f32_to_nhwc_bf16(const float* x, void* out, int N, int C, int HW, int cpad, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && out && N > 0 && C > 0 && HW > 0 && cpad >= C, "nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid((long long)N * HW, 256)), dim3(256), 0, stream, x, (bf16*)out, N, C, HW, cpad);
+    return ddpm_check_launch("nchw_to_nhwc");
+}
+
+// dz = dy * (1 - y^2) for y = tanh(z): turns the gradient arriving at the UNet output (NCHW fp32)
+// into the channel-padded NHWC bf16 gradient of the last convolution's logits.
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, bf16* __restrict__ dz,
+                                                        int N, int C, int HW, int cpad) {
+    const long long total = (long long)N * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW);
+        const int p = (int)(i - (long long)n * HW);
+        for (int c = 0; c < cpad; ++c) {
+            float g = 0.f;
+            if (c < C) {
+                const long long s = ((long long)n * C + c) * HW + p;
+                const float yy = y[s];
+                g = dy[s] * (1.0f - yy * yy);
+            }
+            dz[i * cpad + c] = (bf16)g;
+        }
+    }
+}
+
+extern "C" int ddpm_tanh_bwd_nchw_to_nhwc(const float* dy, const float* y, void* dz, int N, int C, int HW, int cpad, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(dy && y && dz && N > 0 && C > 0 && HW > 0 && cpad >= C, "tanh_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(stream_grid((long long)N * HW, 256)), dim3(256), 0, stream, dy, y, (bf16*)dz, N, C, HW, cpad);
+    return ddpm_check_launch("tanh_bwd");
+}
+
+// NHWC bf16 -> NCHW fp32 (gradient w.r.t. the UNet input, when a caller asks for it).
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16* __restrict__ x, float* __restrict__ out, int N, int C, int HW,
+                                                            int cpad) {
+    const long long total = (long long)N * C * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long long nc = i / HW;
+        const int c = (int)(nc % C);
+        const int n = (int)(nc / C);
+        out[i] = (float)x[((long long)n * HW + p) * cpad + c];
+    }
+}
+
+extern "C" int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int C, int HW, int cpad, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && out && N > 0 && C > 0 && HW > 0 && cpad >= C, "nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_grid((long long)N * C * HW, 256)), dim3(256), 0, stream, (const bf16*)x, out, N, C,
+                       HW, cpad);
+    return ddpm_check_launch("nhwc_to_nchw");
+}
+
+// Advance a device-resident 64-bit seed by one (so a replayed graph draws fresh randomness each step).
+__global__ void bump_seed_kernel(unsigned long long* seed) { *seed += 0x9E3779B97F4A7C15ull; }
+
+extern "C" int ddpm_bump_seed(uint64_t* seed_, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned long long* seed = (unsigned long long*)seed_;
+    DDPM_REQUIRE(seed, "bump_seed: null pointer");
+    hipLaunchKernelGGL(bump_seed_kernel, dim3(1), dim3(1), 0, stream, seed);
+    return ddpm_check_launch("bump_seed");
+}

@@ -1,0 +1,83 @@
+"""ctypes binding of libddpm_hip.so (C ABI declared in include/ddpm_hip.h).
+
+There is no CPU fallback: loading fails loudly when the library has not been built, and every call
+raises RuntimeError with the library's message when an entry point reports an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libddpm_hip.so")
+
+ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5}
+CONV_3X3_S1, CONV_3X3_S2, CONV_1X1, CONVT_2X2_S2, DGRAD_3X3_S2, DGRAD_CONVT_2X2 = range(6)
+OUT_BF16_NHWC, OUT_F32_NCHW = 0, 1
+
+_vp, _i, _f, _i64, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("kind", _i), ("N", _i), ("IH", _i), ("IW", _i),
+        ("in0", _vp), ("in1", _vp), ("C0", _i), ("C1", _i),
+        ("in_add", _vp), ("in_mask", _vp), ("in_mask_scale", _f),
+        ("w", _vp), ("bias", _vp),
+        ("out", _vp), ("res", _vp), ("out_mask", _vp), ("out_mask_scale", _f),
+        ("Cout", _i), ("CoutW", _i), ("out_cs", _i),
+        ("act", _i), ("out_mode", _i),
+    ]
+
+
+_PROTOS = {
+    "ddpm_abi_version": ([], _i),
+    "ddpm_q_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _u32, _vp], _i),
+    "ddpm_reverse_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _u32, _i, _vp], _i),
+    "ddpm_elbo_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
+    "ddpm_elbo_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
+    "ddpm_time_embedding": ([_vp, _f, _i, _vp, _i, _vp], _i),
+    "ddpm_nchw_f32_to_nhwc_bf16": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_nhwc_bf16_to_nchw_f32": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_tanh_bwd_nchw_to_nhwc": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_bump_seed": ([_vp, _vp], _i),
+    "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python diffusion-model_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build the HIP extension first (python diffusion-model_amd/build.py); "
+                               "there is no fallback path")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ddpm_last_error.restype = C.c_char_p
+        for name, (args, res) in _PROTOS.items():
+            fn = getattr(_lib, name)
+            fn.argtypes, fn.restype = args, res
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libddpm_hip {what} failed ({rc}): {lib().ddpm_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    """The hipStream_t torch currently enqueues on (so launches are captured by torch.cuda graphs too)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args), name)

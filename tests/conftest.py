@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import dm_amd_bootstrap  # noqa: F401,E402  (registers the package in ./diffusion-model_amd as `dm_amd`)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -26,3 +28,11 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU test collected on a machine without a GPU"
+    return torch.device("cuda:0")

@@ -1,0 +1,122 @@
+"""GPU parity of the MFMA implicit-GEMM convolution (forward and data-gradient of every kind) against
+torch fp32 CPU convolutions of the same bf16-rounded operands.  Tolerance: 1e-2 of the output scale
+(bf16 storage of the result; accumulation is fp32)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dm_amd.runtime import hip, ops, pack
+from oracle.noise import hash_normal, hash_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def r16(t):
+    return t.bfloat16().float()
+
+
+def nhwc(t, dev, cpad=None):
+    t = t.permute(0, 2, 3, 1)
+    if cpad and cpad > t.shape[3]:
+        t = F.pad(t, (0, cpad - t.shape[3]))
+    return t.contiguous().to(dev).bfloat16()
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def assert_rel(got, ref, tol=1e-2):
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.4g} vs scale {scale:.4g}"
+
+
+CASES = [
+    # kind, N, Cin, Cout, H, W
+    (hip.CONV_3X3_S1, 2, 32, 32, 16, 16),
+    (hip.CONV_3X3_S1, 3, 64, 32, 8, 8),
+    (hip.CONV_3X3_S1, 5, 256, 512, 2, 2),
+    (hip.CONV_3X3_S1, 2, 16, 32, 32, 32),     # stem-like (3 real channels padded to 16)
+    (hip.CONV_3X3_S1, 2, 32, 3, 32, 32),      # image head
+    (hip.CONV_3X3_S1, 1, 32, 64, 12, 20),     # ragged tiles
+    (hip.CONV_3X3_S2, 2, 32, 64, 16, 16),
+    (hip.CONV_3X3_S2, 7, 128, 256, 4, 4),
+    (hip.CONV_1X1, 2, 32, 64, 16, 16),
+    (hip.CONV_1X1, 2, 512, 256, 2, 2),
+    (hip.CONV_1X1, 9, 32, 128, 1, 1),         # nn.Linear of the time-embedding MLP
+    (hip.CONVT_2X2_S2, 2, 64, 32, 8, 8),
+    (hip.CONVT_2X2_S2, 3, 256, 128, 2, 2),
+]
+
+
+def torch_ref(kind, x, w, b):
+    if kind == hip.CONV_3X3_S1:
+        return F.conv2d(x, w, b, padding=1)
+    if kind == hip.CONV_3X3_S2:
+        return F.conv2d(x, w, b, stride=2, padding=1)
+    if kind == hip.CONV_1X1:
+        return F.conv2d(x, w, b)
+    return F.conv_transpose2d(x, w, b, stride=2)
+
+
+@pytest.mark.parametrize("kind,n,ci,co,h,w_", CASES)
+def test_conv_forward_and_dgrad(dev, kind, n, ci, co, h, w_):
+    k = {hip.CONV_3X3_S1: 3, hip.CONV_3X3_S2: 3, hip.CONV_1X1: 1, hip.CONVT_2X2_S2: 2}[kind]
+    wshape = (ci, co, k, k) if kind == hip.CONVT_2X2_S2 else (co, ci, k, k)
+    w = r16(hash_normal(wshape, 1) * (1.0 / (ci * k * k)) ** 0.5)
+    if ci == 16:                                # padded input channels carry zero weights
+        w[:, 3:] = 0
+    b = hash_normal((co,), 2) * 0.1
+    x = r16(hash_normal((n, ci, h, w_), 3))
+    ref = torch_ref(kind, x, w, b)
+    y = ops.conv_forward(kind, nhwc(x, dev), pack.pack_fwd(kind, w.to(dev)), b.to(dev), co, out_cs=(co + 7) // 8 * 8)
+    assert_rel(nchw(y)[:, :co], ref)
+    # data gradient: dX = conv_dgrad(dY)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    xg = x.clone().requires_grad_(True)
+    (gref,) = torch.autograd.grad(torch_ref(kind, xg, w, None), xg, gy)
+    copad = (co + 15) // 16 * 16
+    gx = ops.conv_forward(pack.DGRAD_KIND[kind], nhwc(gy, dev, copad), pack.pack_dgrad(kind, w.to(dev)), None, ci)
+    assert_rel(nchw(gx), gref)
+
+
+def test_conv_fused_input_and_epilogue(dev):
+    """two-source concat + time-embedding add + input dropout mask; activation, output mask, residual."""
+    n, c0, c1, co, h = 3, 64, 64, 64, 8
+    x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))
+    temb = hash_normal((n, c0), 3)
+    w = r16(hash_normal((co, c0 + c1, 3, 3), 4) * 0.04)
+    b = hash_normal((co,), 5) * 0.1
+    keep = (hash_uniform((n, h, h, c0), 6) < 0.9)
+    res = r16(hash_normal((n, co, h, h), 7))
+    okeep = (hash_uniform((n, h, h, co), 8) < 0.8)
+
+    def bits(k):
+        return (k.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
+
+    xin = r16(x0 + temb[:, :, None, None]) * keep.permute(0, 3, 1, 2) / 0.9
+    ref = F.gelu(F.conv2d(torch.cat([r16(xin), x1], 1), w, b, padding=1))
+    ref = ref * okeep.permute(0, 3, 1, 2) / 0.8 + res
+    y = ops.conv_forward(hip.CONV_3X3_S1, nhwc(x0, dev), pack.pack_fwd(hip.CONV_3X3_S1, w.to(dev)), b.to(dev), co, x1=nhwc(x1, dev),
+                         in_add=temb.to(dev), in_mask=bits(keep).to(dev), in_scale=1 / 0.9, act=hip.ACT["gelu"], res=nhwc(res, dev),
+                         out_mask=bits(okeep).to(dev), out_scale=1 / 0.8)
+    assert_rel(nchw(y), ref, 1.5e-2)
+
+
+def test_conv_head_f32_nchw_tanh(dev):
+    n, ci, co, h = 2, 32, 3, 16
+    x = r16(hash_normal((n, ci, h, h), 1))
+    w = r16(hash_normal((co, ci, 3, 3), 2) * 0.06)
+    b = hash_normal((co,), 3) * 0.1
+    ref = torch.tanh(F.conv2d(x, w, b, padding=1))
+    y = ops.conv_forward(hip.CONV_3X3_S1, nhwc(x, dev), pack.pack_fwd(hip.CONV_3X3_S1, w.to(dev)), b.to(dev), co, act=hip.ACT["tanh"],
+                         f32_nchw=True)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_conv_rejects_bad_shapes(dev):
+    x = torch.zeros(1, 4, 4, 24, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(1, 32, 24, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        ops.conv_forward(hip.CONV_1X1, x, w, None, 32)

@@ -1,0 +1,105 @@
+"""GPU parity of the fused diffusion elementwise kernels against the CPU oracle (through the C ABI)."""
+import pytest
+import torch
+
+from dm_amd.runtime import hip
+from oracle import ref_cpu as O
+from oracle.noise import hash_normal, hash_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def sched_table(T=120, beta=0.25):
+    """fp32 [T+1][8] table built from the oracle's schedule tensors, the way the host code does."""
+    s = O.make_schedule(T, beta)
+    tab = torch.zeros(T + 1, 8)
+    t = torch.arange(1, T + 1)
+    tab[1:, 0] = s["sqrt_alphas_bar"][t].flatten()
+    tab[1:, 1] = s["sqrt_one_minus_alphas_bar"][t].flatten()
+    tab[1:, 2] = (s["one_minus_alphas_bar"][t - 1] * s["x_previous_coef"][t]).flatten()
+    tab[1:, 3] = (s["sqrt_alphas_bar"][t - 1] * s["x0_pred_coef"][t]).flatten()
+    tab[1:, 4] = (s["sqrt_one_minus_alphas_bar"][t - 1] * s["bw_std"][t]).flatten()
+    tab[1:, 5] = O.elbo_weight(s, t).flatten()
+    return s, tab
+
+
+def test_q_and_reverse_bit_exact_vs_golden(golden, dev):
+    g = golden("diffusion_ops.pt")
+    _, tab = sched_table()
+    tab = tab.to(dev)
+    n, c, h, w = g["x0"].shape
+    x0, t, eps = g["x0"].to(dev), g["t"].to(dev), g["eps"].to(dev)
+    xt = torch.empty_like(x0)
+    xt_nhwc = torch.full((n, h, w, 16), 7.0, device=dev, dtype=torch.bfloat16)
+    hip.call("ddpm_q_sample", hip.ptr(x0), hip.ptr(t), hip.ptr(eps), hip.ptr(tab), hip.ptr(xt), hip.ptr(xt_nhwc), 16, n, c, h * w,
+             None, 0, hip.stream())
+    assert torch.equal(xt.cpu(), g["x_t"])
+    assert torch.equal(xt_nhwc[..., :c].float().cpu(), g["x_t"].permute(0, 2, 3, 1).bfloat16().float())
+    assert (xt_nhwc[..., c:] == 0).all()
+    out = torch.empty_like(x0)
+    hip.call("ddpm_reverse_step", hip.ptr(xt), hip.ptr(g["x0_pred"].to(dev)), hip.ptr(t), hip.ptr(g["z"].to(dev)), hip.ptr(tab),
+             hip.ptr(out), n, c * h * w, None, 0, 0, hip.stream())
+    assert torch.equal(out.cpu(), g["x_prev"])
+
+
+def test_elbo_fwd_bwd(golden, dev):
+    g = golden("diffusion_ops.pt")
+    _, tab = sched_table()
+    tab = tab.to(dev)
+    n, c, h, w = g["x0"].shape
+    pred, x0, t = g["x0_pred"].to(dev), g["x0"].to(dev), g["t"].to(dev)
+    loss = torch.zeros(1, device=dev)
+    hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr(x0), hip.ptr(t), hip.ptr(tab), hip.ptr(loss), n, c * h * w, 0, 1, hip.stream())
+    torch.testing.assert_close(loss.cpu()[0], g["loss_mse"], rtol=1e-5, atol=1e-7)
+    gp = torch.empty_like(pred)
+    hip.call("ddpm_elbo_bwd", hip.ptr(pred), hip.ptr(x0), hip.ptr(t), hip.ptr(tab), None, hip.ptr(gp), n, c * h * w, 0, 1, hip.stream())
+    torch.testing.assert_close(gp.cpu(), g["grad_mse"], rtol=1e-5, atol=1e-9)
+    hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr((x0 + 1) / 2), hip.ptr(t), hip.ptr(tab), hip.ptr(loss), n, c * h * w, 1, 1, hip.stream())
+    torch.testing.assert_close(loss.cpu()[0], g["loss_bce"], rtol=1e-5, atol=1e-7)
+    hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr(x0), hip.ptr(t), hip.ptr(tab), hip.ptr(loss), n, c * h * w, 0, 0, hip.stream())
+    torch.testing.assert_close(loss.cpu()[0], g["loss_plain"], rtol=1e-5, atol=1e-7)
+
+
+def test_in_kernel_noise_is_standard_normal_and_seeded(dev):
+    n, c, hw = 64, 3, 1024
+    _, tab = sched_table()
+    tab = tab.to(dev)
+    x0 = torch.zeros(n, c, hw, device=dev)
+    t = torch.full((n,), 120, device=dev, dtype=torch.long)
+    seed = torch.tensor([1234], device=dev, dtype=torch.int64)
+    a, b = torch.empty_like(x0), torch.empty_like(x0)
+    hip.call("ddpm_q_sample", hip.ptr(x0), hip.ptr(t), None, hip.ptr(tab), hip.ptr(a), None, 0, n, c, hw, hip.ptr(seed), 3, hip.stream())
+    hip.call("ddpm_q_sample", hip.ptr(x0), hip.ptr(t), None, hip.ptr(tab), hip.ptr(b), None, 0, n, c, hw, hip.ptr(seed), 3, hip.stream())
+    assert torch.equal(a, b)
+    z = a / tab[120, 1]
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1.0) < 0.01
+    assert abs((z ** 4).mean().item() - 3.0) < 0.1
+    hip.call("ddpm_bump_seed", hip.ptr(seed), hip.stream())
+    hip.call("ddpm_q_sample", hip.ptr(x0), hip.ptr(t), None, hip.ptr(tab), hip.ptr(b), None, 0, n, c, hw, hip.ptr(seed), 3, hip.stream())
+    assert not torch.equal(a, b)
+    assert abs(torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1].item()) < 0.01
+
+
+def test_time_embedding(golden, dev):
+    e = golden("blocks.pt")["embed.gelu"]
+    t = e["t"].to(dev)
+    out = torch.empty(t.numel(), 32, device=dev, dtype=torch.bfloat16)
+    hip.call("ddpm_time_embedding", hip.ptr(t), 100.0, 32, hip.ptr(out), t.numel(), hip.stream())
+    torch.testing.assert_close(out.float().cpu(), e["sin"], rtol=1e-2, atol=4e-3)
+
+
+def test_layout_bridges(dev):
+    x = hash_normal((3, 3, 8, 8), 5).to(dev)
+    nhwc = torch.empty(3, 8, 8, 16, device=dev, dtype=torch.bfloat16)
+    hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(nhwc), 3, 3, 64, 16, hip.stream())
+    assert torch.equal(nhwc[..., :3].permute(0, 3, 1, 2).float(), x.bfloat16().float())
+    assert (nhwc[..., 3:] == 0).all()
+    back = torch.empty_like(x)
+    hip.call("ddpm_nhwc_bf16_to_nchw_f32", hip.ptr(nhwc), hip.ptr(back), 3, 3, 64, 16, hip.stream())
+    assert torch.equal(back, x.bfloat16().float())
+    y = torch.tanh(x)
+    dy = hash_normal((3, 3, 8, 8), 6).to(dev)
+    dz = torch.empty_like(nhwc)
+    hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(y), hip.ptr(dz), 3, 3, 64, 16, hip.stream())
+    ref = (dy * (1 - y * y)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(dz[..., :3].float(), ref, rtol=1e-2, atol=1e-3)
