@@ -8,6 +8,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+// q / reverse step are checked bit-for-bit against the reference arithmetic (separately rounded
+// multiplies and adds), so the compiler must not contract a*b+c into an FMA in this file.
+#pragma clang fp contract(off)
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing shared by the whole library
 static thread_local char g_err[512] = "";
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
         const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, stream_id, (unsigned long long)q);
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(a, x[j]), __fmul_rn(b, z[j]));
+        for (int j = 0; j < 4; ++j) o[j] = a * x[j] + b * z[j];   // two roundings + one: no FMA (contract off)
         if (xt) *(f32x4*)(xt + e) = o;
         if (xt_nhwc) {
             const long long r = e - (long long)n * chw;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (sigmoid_pred) p[j] = 1.0f / (1.0f + __expf(-p[j]));
-            o[j] = __fadd_rn(__fadd_rn(__fmul_rn(A, x[j]), __fmul_rn(B, p[j])), __fmul_rn(Cc, z[j]));
+            o[j] = (A * x[j] + B * p[j]) + Cc * z[j];   // same association as the reference, no FMA
         }
         *(f32x4*)(out + e) = o;
     }

@@ -9,9 +9,18 @@ from oracle.noise import hash_normal, hash_uniform
 pytestmark = pytest.mark.gpu
 
 
-def sched_table(T=120, beta=0.25):
-    """fp32 [T+1][8] table built from the oracle's schedule tensors, the way the host code does."""
-    s = O.make_schedule(T, beta)
+def same(a, b):
+    """bit-exact comparison with a short failure message"""
+    d = (a.double() - b.double()).abs().max().item()
+    assert torch.equal(a, b), f"max abs diff {d:.3e}"
+
+
+def sched_table(golden):
+    """fp32 [T+1][8] table built, the way the host code does, from the schedule tensors the reference produced in
+    the build container (linspace/cumprod round differently by one ulp on other CPUs, so bit-exact checks must start
+    from the stored tables rather than recompute them here)."""
+    s = dict(golden("schedule_T120_b025.pt")["tables"])
+    T = 120
     tab = torch.zeros(T + 1, 8)
     t = torch.arange(1, T + 1)
     tab[1:, 0] = s["sqrt_alphas_bar"][t].flatten()
@@ -25,7 +34,7 @@ def sched_table(T=120, beta=0.25):
 
 def test_q_and_reverse_bit_exact_vs_golden(golden, dev):
     g = golden("diffusion_ops.pt")
-    _, tab = sched_table()
+    _, tab = sched_table(golden)
     tab = tab.to(dev)
     n, c, h, w = g["x0"].shape
     x0, t, eps = g["x0"].to(dev), g["t"].to(dev), g["eps"].to(dev)
@@ -33,18 +42,19 @@ def test_q_and_reverse_bit_exact_vs_golden(golden, dev):
     xt_nhwc = torch.full((n, h, w, 16), 7.0, device=dev, dtype=torch.bfloat16)
     hip.call("ddpm_q_sample", hip.ptr(x0), hip.ptr(t), hip.ptr(eps), hip.ptr(tab), hip.ptr(xt), hip.ptr(xt_nhwc), 16, n, c, h * w,
              None, 0, hip.stream())
-    assert torch.equal(xt.cpu(), g["x_t"])
-    assert torch.equal(xt_nhwc[..., :c].float().cpu(), g["x_t"].permute(0, 2, 3, 1).bfloat16().float())
+    same(xt.cpu(), g["x_t"])
+    same(xt_nhwc[..., :c].float().cpu(), g["x_t"].permute(0, 2, 3, 1).bfloat16().float())
     assert (xt_nhwc[..., c:] == 0).all()
     out = torch.empty_like(x0)
-    hip.call("ddpm_reverse_step", hip.ptr(xt), hip.ptr(g["x0_pred"].to(dev)), hip.ptr(t), hip.ptr(g["z"].to(dev)), hip.ptr(tab),
+    x0p, z = g["x0_pred"].to(dev), g["z"].to(dev)       # keep references: only raw pointers cross the ABI
+    hip.call("ddpm_reverse_step", hip.ptr(xt), hip.ptr(x0p), hip.ptr(t), hip.ptr(z), hip.ptr(tab),
              hip.ptr(out), n, c * h * w, None, 0, 0, hip.stream())
-    assert torch.equal(out.cpu(), g["x_prev"])
+    same(out.cpu(), g["x_prev"])
 
 
 def test_elbo_fwd_bwd(golden, dev):
     g = golden("diffusion_ops.pt")
-    _, tab = sched_table()
+    _, tab = sched_table(golden)
     tab = tab.to(dev)
     n, c, h, w = g["x0"].shape
     pred, x0, t = g["x0_pred"].to(dev), g["x0"].to(dev), g["t"].to(dev)
@@ -54,15 +64,16 @@ def test_elbo_fwd_bwd(golden, dev):
     gp = torch.empty_like(pred)
     hip.call("ddpm_elbo_bwd", hip.ptr(pred), hip.ptr(x0), hip.ptr(t), hip.ptr(tab), None, hip.ptr(gp), n, c * h * w, 0, 1, hip.stream())
     torch.testing.assert_close(gp.cpu(), g["grad_mse"], rtol=1e-5, atol=1e-9)
-    hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr((x0 + 1) / 2), hip.ptr(t), hip.ptr(tab), hip.ptr(loss), n, c * h * w, 1, 1, hip.stream())
+    y01 = (x0 + 1) / 2
+    hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr(y01), hip.ptr(t), hip.ptr(tab), hip.ptr(loss), n, c * h * w, 1, 1, hip.stream())
     torch.testing.assert_close(loss.cpu()[0], g["loss_bce"], rtol=1e-5, atol=1e-7)
     hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr(x0), hip.ptr(t), hip.ptr(tab), hip.ptr(loss), n, c * h * w, 0, 0, hip.stream())
     torch.testing.assert_close(loss.cpu()[0], g["loss_plain"], rtol=1e-5, atol=1e-7)
 
 
-def test_in_kernel_noise_is_standard_normal_and_seeded(dev):
+def test_in_kernel_noise_is_standard_normal_and_seeded(golden, dev):
     n, c, hw = 64, 3, 1024
-    _, tab = sched_table()
+    _, tab = sched_table(golden)
     tab = tab.to(dev)
     x0 = torch.zeros(n, c, hw, device=dev)
     t = torch.full((n,), 120, device=dev, dtype=torch.long)
