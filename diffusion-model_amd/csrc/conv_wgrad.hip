@@ -1,0 +1,231 @@
+// Weight gradient of the dense convolutions on bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+//   dW[slice_j][co][ci] += sum over positions p of  dY[out pixel of p][co] * X[in pixel of p shifted by tap j][ci]
+//
+// GEMM view: the contraction runs over POSITIONS (N*GH*GW, the long dimension), the output is the small
+// [taps][Cout][Cin] weight block.  Both operands are stored pixel-major (NHWC), i.e. [k][row] from the
+// MFMA's point of view, so their fragments are fetched from LDS with the transposing read
+// ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group, delivered column-major).
+//
+// A workgroup owns (32*NCO output channels) x (32 input channels) x (all taps of its class) and walks a
+// strided subset of the position tiles.  Per tile it stages the dY tile and the input patch (with halo,
+// with the same fused input transforms as the forward kernel: concat, time-embedding add, dropout mask)
+// once; the (tap, co-subtile) work items are dealt round-robin to the 4 waves, each keeping its items'
+// 32x32 fp32 accumulators in registers across all tiles.  One atomic flush per workgroup at the end.
+#include "conv_geom.h"
+#include "ddpm_hip.h"
+
+struct WgradArgs {
+    ConvGeom g;
+    const bf16* in0; const bf16* in1; int C0, C1;
+    const float* in_add; const unsigned char* in_mask; float in_mask_scale;
+    const bf16* dy; int Cout, dy_cs;
+    float* dw;
+    int ntiles;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+    // two transposed 4x16 block reads -> the 8 k-values of this lane's row/column
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int NCO, int MAXI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int T = 256, BM = 128;
+    constexpr int DYS = NCO * 64 + 16;          // dY tile row stride (bytes)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cls = blockIdx.z;
+    const int tap0 = g.cls_tap_begin[cls], ntaps = g.cls_tap_begin[cls + 1] - tap0;
+    const int Cin = a.C0 + a.C1;
+    const int nci = (Cin + CONV_CK - 1) / CONV_CK;
+    const int cob = blockIdx.y / nci, cib = blockIdx.y - cob * nci;
+    const int co0 = cob * 32 * NCO, c0 = cib * CONV_CK;
+    const int parts = (Cin - c0 >= CONV_CK) ? 4 : (Cin - c0) / 8;
+    const int PHW = g.PH * g.PW, npix = g.NB * PHW;
+    const int thw = g.TH * g.TW;
+    const int offh = g.cls_off_h[cls], offw = g.cls_off_w[cls];
+
+    int* s_pl = (int*)smem;                                        // patch slot -> linear input pixel or -1
+    int* s_pb = s_pl + ((npix + 3) & ~3);                          // position -> patch pixel base
+    int* s_po = s_pb + BM;                                         // position -> linear output pixel or -1
+    char* s_patch = (char*)(s_po + BM);
+    char* s_dy = s_patch + npix * CONV_RS;
+
+    for (int p = tid; p < BM; p += T) {
+        const int il = p / thw, rem = p - il * thw;
+        const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        s_pb[p] = il * PHW + ty * g.SI * g.PW + tx * g.SI;
+    }
+
+    const bool src1 = c0 >= a.C0;
+    const bf16* src = src1 ? a.in1 : a.in0;
+    const int cs = src1 ? a.C1 : a.C0, cc = src1 ? c0 - a.C0 : c0;
+    const int ihw = g.IH * g.IW;
+
+    // work items of this wave: item = tap * NCO + co-subtile, dealt round-robin
+    const int nitems = ntaps * NCO;
+    f32x16 acc[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // lane-constant parts of the transposed-read addresses
+    const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int kq = 8 * (grp >> 1) + q;                 // k row supplied by this lane (first read); +4 for the second
+    const int colb = (16 * (grp & 1) + 4 * pp) * 2;    // byte offset of its 4 columns inside a 32-channel row
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int twi = t % g.tiles_w; t /= g.tiles_w;
+        const int thi = t % g.tiles_h;
+        const int tni = t / g.tiles_h;
+        const int n0 = tni * g.NB, oy = thi * g.TH, ox = twi * g.TW;
+        __syncthreads();     // previous tile fully consumed
+        for (int p = tid; p < npix; p += T) {
+            const int il = p / PHW, r = p - il * PHW;
+            const int py = r / g.PW, px = r - py * g.PW;
+            const int n = n0 + il, iy = oy * g.SI + g.dmin_h + py, ix = ox * g.SI + g.dmin_w + px;
+            const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            s_pl[p] = ok ? (n * g.IH + iy) * g.IW + ix : -1;
+        }
+        for (int p = tid; p < BM; p += T) {
+            const int il = p / thw, rem = p - il * thw;
+            const int ty = rem / g.TW, tx = rem - ty * g.TW;
+            const int n = n0 + il, py = oy + ty, px = ox + tx;
+            const int oh = py * g.SO + offh, ow = px * g.SO + offw;
+            const bool ok = n < g.N && py < g.GH && px < g.GW && oh < g.OH && ow < g.OW;
+            s_po[p] = ok ? (n * g.OH + oh) * g.OW + ow : -1;
+        }
+        __syncthreads();
+        // -- stage the input patch (32 channels of this block's chunk)
+        for (int it = tid; it < npix * 4; it += T) {
+            const int p = it >> 2, part = it & 3;
+            if (part >= parts) continue;
+            const int pl = s_pl[p];
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+            if (pl >= 0) {
+                const long long e = (long long)pl * cs + cc + part * 8;
+                v = *(const bf16x8*)(src + e);
+                if (!src1) {
+                    if (a.in_add) {
+                        const float* ad = a.in_add + (pl / ihw) * a.C0 + cc + part * 8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + ad[j]);
+                    }
+                    if (a.in_mask) {
+                        const unsigned m = a.in_mask[e >> 3];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.in_mask_scale) : (bf16)0.f;
+                    }
+                }
+            }
+            *(bf16x8*)(s_patch + p * CONV_RS + part * 16) = v;
+        }
+        // -- stage the dY tile: BM positions x (32*NCO) output channels, zero rows for masked positions
+        for (int it = tid; it < BM * NCO * 4; it += T) {
+            const int p = it / (NCO * 4), part = it - p * (NCO * 4);
+            const int po = s_po[p];
+            const int co = co0 + part * 8;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+            if (po >= 0 && co + 8 <= a.dy_cs) v = *(const bf16x8*)(a.dy + (long long)po * a.dy_cs + co);
+            *(bf16x8*)(s_dy + p * DYS + part * 16) = v;
+        }
+        __syncthreads();
+        // -- MFMA: for each of this wave's items, contract over the tile's 128 positions (8 k-steps of 16)
+        if (parts >= 2) {
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int item = wave + 4 * i;
+                if (item < nitems) {
+                    const int j = item / NCO, cosub = item - j * NCO;
+                    const int poff = g.tap_poff[tap0 + j] * CONV_RS;
+                    const char* dyp = s_dy + cosub * 64 + colb;
+                    for (int ks = 0; ks < BM / 16; ++ks) {
+                        const int k = ks * 16 + kq;
+                        const bf16x8 av = tr_frag(dyp + k * DYS, dyp + (k + 4) * DYS);
+                        const bf16x8 bv = tr_frag(s_patch + s_pb[k] * CONV_RS + poff + colb, s_patch + s_pb[k + 4] * CONV_RS + poff + colb);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- flush: dw[slice][co][ci] += acc  (rows = co, columns = ci)
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int item = wave + 4 * i;
+        if (item >= nitems) continue;
+        const int j = item / NCO, cosub = item - j * NCO;
+        const int ci = c0 + (lane & 31);
+        float* base = a.dw + (long long)g.tap_slice[tap0 + j] * a.Cout * Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cosub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < a.Cout && ci < Cin) atomicAdd(base + (long long)co * Cin + ci, acc[i][r]);
+        }
+    }
+}
+
+template <int NCO, int MAXI>
+static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto k = conv_wgrad_kernel<NCO, MAXI>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ddpm_check_launch("wgrad: raise dynamic LDS limit");
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, a);
+    return ddpm_check_launch("conv_wgrad");
+}
+
+extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(d && d->in0 && d->dy && d->dw, "wgrad: null pointer");
+    DDPM_REQUIRE(d->kind == CONV_3X3_S1 || d->kind == CONV_3X3_S2 || d->kind == CONV_1X1 || d->kind == CONVT_2X2_S2,
+                 "wgrad: kind %d is not a forward kind", d->kind);
+    DDPM_REQUIRE(d->N > 0 && d->IH > 0 && d->IW > 0, "wgrad: bad dims");
+    DDPM_REQUIRE(d->C0 > 0 && d->C0 % 16 == 0 && d->C1 >= 0 && d->C1 % 32 == 0 && (d->C1 == 0 || (d->in1 && d->C0 % 32 == 0)),
+                 "wgrad: input channels must be multiples of 16 (32 when two sources are concatenated); got %d + %d", d->C0, d->C1);
+    DDPM_REQUIRE(d->Cout > 0 && d->dy_cs >= d->Cout && d->dy_cs % 8 == 0, "wgrad: dy channel stride %d must be a multiple of 8 >= Cout %d",
+                 d->dy_cs, d->Cout);
+    WgradArgs a;
+    if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 128) != 0) { ddpm_set_error("wgrad: geometry"); return DDPM_EINVAL; }
+    a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1;
+    a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
+    a.dy = (const bf16*)d->dy; a.Cout = d->Cout; a.dy_cs = d->dy_cs; a.dw = d->dw;
+    a.ntiles = a.g.tiles_n * a.g.tiles_h * a.g.tiles_w;
+    const int Cin = d->C0 + d->C1;
+    const int co_sub = (d->Cout + 31) / 32;
+    int nco = a.g.max_taps >= 9 ? 2 : 4;
+    if (nco > co_sub) nco = co_sub;
+    if (nco == 3) nco = 2;
+    const int cob = (co_sub + nco - 1) / nco, nci = (Cin + CONV_CK - 1) / CONV_CK;
+    const int maxi = (a.g.max_taps * nco + 3) / 4;
+    long long other = (long long)cob * nci * a.g.ncls;
+    long long msplit = 512 / other;
+    if (msplit < 1) msplit = 1;
+    if (msplit > a.ntiles) msplit = a.ntiles;
+    const int npix = a.g.NB * a.g.PH * a.g.PW;
+    const size_t lds = ((size_t)((npix + 3) & ~3) + 128 + 128) * 4 + (size_t)npix * CONV_RS + (size_t)128 * (nco * 64 + 16);
+    DDPM_REQUIRE(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS", lds);
+    dim3 grid((unsigned)msplit, (unsigned)(cob * nci), (unsigned)a.g.ncls);
+#define WG_CASE(NCOv, MAXIv) if (nco == NCOv && maxi == MAXIv) return launch_wgrad<NCOv, MAXIv>(a, grid, lds, stream);
+    WG_CASE(1, 1) WG_CASE(2, 1) WG_CASE(4, 1)      /* 1-tap classes: 1x1, convT */
+    WG_CASE(1, 3) WG_CASE(2, 5)                    /* 9 taps */
+#undef WG_CASE
+    ddpm_set_error("wgrad: no kernel for nco=%d items/wave=%d", nco, maxi);
+    return DDPM_EINVAL;
+}

@@ -311,3 +311,119 @@ extern "C" int ddpm_bump_seed(uint64_t* seed_, ddpm_stream_t stream_) {
     hipLaunchKernelGGL(bump_seed_kernel, dim3(1), dim3(1), 0, stream, seed);
     return ddpm_check_launch("bump_seed");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of an NHWC bf16 matrix [rows][cs] -> fp32 [C] (+=): the bias gradient of a convolution whose
+// output gradient is not produced by a GroupNorm backward (the image head, the time-embedding MLPs).
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, long long rows, int C, int cs,
+                                                      int rows_per_block) {
+    const int cvs = cs / 8;
+    const int cv = threadIdx.x % cvs, prow = threadIdx.x / cvs, pstep = 256 / cvs;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (prow < pstep) {
+        for (long long r = r0 + prow; r < r1; r += pstep) {
+            const bf16x8 v = *(const bf16x8*)(x + r * cs + cv * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int lo = cvs < 64 ? cvs : 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = s[j];
+        for (int o = 32; o >= lo; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int c = cv * 8 + j;
+        if (lane < lo && c < C) atomicAdd(out + c, v);
+    }
+}
+
+extern "C" int ddpm_colsum(const void* x, float* out, int64_t rows, int C, int cs, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && out && rows > 0 && C > 0 && cs >= C && cs % 8 == 0, "colsum: bad arguments");
+    const int cvs = cs / 8;
+    DDPM_REQUIRE(cvs <= 64 && (cvs & (cvs - 1)) == 0, "colsum: channel stride %d must be 8 * a power of two <= 512", cs);
+    long long blocks = (rows * cvs + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const int rpb = (int)((rows + blocks - 1) / blocks);
+    blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, out, (long long)rows, C, cs, rpb);
+    return ddpm_check_launch("colsum");
+}
+
+// out[n][c] = sum_p x[n][p][c]  (fp32, overwritten): gradient of the broadcast time-embedding add.
+// One workgroup per (image, 64-channel slab).
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const bf16* __restrict__ x, float* __restrict__ out, int HW, int C, int SC) {
+    __shared__ float s_red[4 * 64];
+    const int slabs = C / SC;
+    const int n = blockIdx.x / slabs, c0 = (blockIdx.x - n * slabs) * SC;
+    const int vps = SC / 8;
+    const int cv = threadIdx.x % vps, prow = threadIdx.x / vps, pstep = 256 / vps;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (int p = prow; p < HW; p += pstep) {
+        const bf16x8 v = *(const bf16x8*)(x + ((long long)n * HW + p) * C + c0 + cv * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = s[j];
+        for (int o = 32; o >= vps; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane < vps) s_red[wave * 64 + lane * 8 + j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < SC) out[(long long)n * C + c0 + threadIdx.x] = s_red[threadIdx.x] + s_red[64 + threadIdx.x] + s_red[128 + threadIdx.x] + s_red[192 + threadIdx.x];
+}
+
+extern "C" int ddpm_spatial_sum(const void* x, float* out, int N, int HW, int C, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && out && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "spatial_sum: bad arguments");
+    int sc = C < 64 ? C : 64;
+    while (C % sc) sc -= 8;
+    DDPM_REQUIRE(sc == 8 || sc == 16 || sc == 32 || sc == 64, "spatial_sum: unsupported channel count %d", C);
+    hipLaunchKernelGGL(spatial_sum_kernel, dim3(N * (C / sc)), dim3(256), 0, stream, (const bf16*)x, out, HW, C, sc);
+    return ddpm_check_launch("spatial_sum");
+}
+
+// Dropout keep bits for all sites of a step in one launch.  Byte b of site s holds the keep decisions of the
+// 8 consecutive elements 8b..8b+7 of that site's tensor; 16 bytes (128 elements) per thread.
+__global__ __launch_bounds__(256) void dropout_masks_kernel(unsigned char* __restrict__ bytes, const long long* __restrict__ offsets,
+                                                             int nsites, long long total_bytes, unsigned thresh,
+                                                             const unsigned long long* __restrict__ seed) {
+    const unsigned long long sd = *seed;
+    for (long long i = (blockIdx.x * 256ll + threadIdx.x) * 4; i < total_bytes; i += (long long)gridDim.x * 256 * 4) {
+        // site of byte i: offsets is a short ascending table; linear scan (nsites <= a few dozen)
+        int s = 0;
+        while (s + 1 < nsites && offsets[s + 1] <= i) ++s;
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const long long bi = i + b;
+            int sb = s;
+            while (sb + 1 < nsites && offsets[sb + 1] <= bi) ++sb;
+            word |= dropout_keep8(sd, (unsigned)sb, (unsigned long long)(bi - offsets[sb]), thresh) << (8 * b);
+        }
+        if (i + 4 <= total_bytes) *(unsigned*)(bytes + i) = word;
+        else for (int b = 0; b < 4 && i + b < total_bytes; ++b) bytes[i + b] = (unsigned char)(word >> (8 * b));
+    }
+}
+
+extern "C" int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int nsites, int64_t total_bytes, float keep,
+                                  const uint64_t* seed, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(bytes && offsets && seed && nsites > 0 && total_bytes > 0 && total_bytes % 4 == 0, "dropout_masks: bad arguments");
+    DDPM_REQUIRE(keep > 0.f && keep <= 1.f, "dropout_masks: keep probability %f out of range", (double)keep);
+    const unsigned thresh = (unsigned)(keep * 65536.0f + 0.5f);
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3(stream_grid(total_bytes / 4, 256)), dim3(256), 0, stream, bytes,
+                       (const long long*)offsets, nsites, (long long)total_bytes, thresh, (const unsigned long long*)seed);
+    return ddpm_check_launch("dropout_masks");
+}

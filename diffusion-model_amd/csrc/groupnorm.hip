@@ -1,0 +1,292 @@
+// GroupNorm fused with activation, dropout mask and residual add, forward and backward, on NHWC bf16.
+//
+// Work unit = one image x one SLAB of channels (a run of whole groups, up to 64 channels wide so that
+// the lanes of a wave read contiguous 16-byte pieces of the same pixel).  A unit is owned by one workgroup
+// (256 threads, or a single wave when the unit is small), which makes the statistics deterministic and
+// needs no atomics in the forward pass.  Each thread owns one 8-channel vector column of the slab and
+// walks the pixels; statistics are fp32, reduced with wave shuffles then across waves through LDS.
+// The second pass re-reads the slab (an L2 hit: a slab is at most a few hundred KB) and writes the result.
+//
+// With groups == 0 the kernels skip normalisation and apply only the activation (the reference's
+// conv -> activation sites without a norm: unets.py:50-51,179-180; constituent_blocks.py:309-311).
+#include "common.h"
+#include "ddpm_hip.h"
+
+struct GnArgs {
+    const bf16* x;             // [N][HW][C] raw convolution output
+    const float* gamma;        // [C]
+    const float* beta;         // [C]
+    const bf16* res;           // optional residual, added last
+    const unsigned char* mask; // optional dropout keep bits of the OUTPUT (1 byte / 8 elements)
+    float mask_scale;
+    bf16* y;                   // forward output / backward: dx
+    float* stats;              // [N][G][2] mean, rstd (written by forward, read by backward)
+    // backward only
+    const bf16* dy;
+    float* dgamma; float* dbeta;   // [C] fp32, accumulated with atomics (caller zeroes)
+    float* dbias;                  // [C] fp32: sum of dx over n,h,w = gradient of the producing conv's bias (nullable)
+    int N, HW, C, G, SC;           // SC = slab width (channels)
+    int act;
+    float eps;
+};
+
+template <int THREADS>
+__device__ __forceinline__ void block_reduce_cols(float (&v)[8], int vps, float* s_red /* [THREADS/64][64] */, int tid) {
+    // sum v[] over all threads with the same (tid % vps); result valid in every thread afterwards.
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = v[j];
+        for (int o = 32; o >= vps; o >>= 1) a += __shfl_xor(a, o, 64);
+        v[j] = a;
+    }
+    if constexpr (THREADS > 64) {
+        const int wave = tid >> 6, lane = tid & 63;
+        __syncthreads();
+        if (lane < vps) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_red[wave * 64 + lane * 8 + j] = v[j];
+        }
+        __syncthreads();
+        const int cv = lane % vps;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) a += s_red[w * 64 + cv * 8 + j];
+            v[j] = a;
+        }
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
+    __shared__ float s_red[256];
+    __shared__ float s_mean[32], s_rstd[32];
+    const int tid = threadIdx.x;
+    const int slabs = a.C / a.SC;
+    const int n = blockIdx.x / slabs, c0 = (blockIdx.x - n * slabs) * a.SC;
+    const int vps = a.SC / 8;                 // vectors per pixel in the slab (power of two, <= 8)
+    const int cv = tid % vps, prow = tid / vps, pstep = THREADS / vps;
+    const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
+    const int cpg = a.G > 0 ? a.C / a.G : 1;
+
+    if (a.G > 0) {
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+        for (int p = prow; p < a.HW; p += pstep) {
+            const bf16x8 v = *(const bf16x8*)(a.x + base + (long long)p * a.C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[j];
+                s[j] += f; ss[j] += f * f;
+            }
+        }
+        block_reduce_cols<THREADS>(s, vps, s_red, tid);
+        block_reduce_cols<THREADS>(ss, vps, s_red, tid);
+        // per-channel sums of this thread's vector -> LDS, then one thread per group finishes
+        __syncthreads();
+        if (tid < vps) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s_red[tid * 8 + j] = s[j]; s_red[64 + tid * 8 + j] = ss[j]; }
+        }
+        __syncthreads();
+        const int ngrp = a.SC / cpg;
+        if (tid < ngrp) {
+            float S = 0.f, SS = 0.f;
+            for (int c = 0; c < cpg; ++c) { S += s_red[tid * cpg + c]; SS += s_red[64 + tid * cpg + c]; }
+            const float m = 1.0f / (float)(cpg * a.HW);
+            const float mean = S * m;
+            const float var = fmaxf(SS * m - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + a.eps);
+            s_mean[tid] = mean; s_rstd[tid] = rstd;
+            if (a.stats) {
+                const int g = c0 / cpg + tid;
+                a.stats[((long long)n * a.G + g) * 2 + 0] = mean;
+                a.stats[((long long)n * a.G + g) * 2 + 1] = rstd;
+            }
+        }
+        __syncthreads();
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (a.G > 0) {
+            const int cl = cv * 8 + j, g = cl / cpg;
+            const float ga = a.gamma[c0 + cl] * s_rstd[g];
+            sc[j] = ga; sh[j] = a.beta[c0 + cl] - s_mean[g] * ga;
+        } else {
+            sc[j] = 1.f; sh[j] = 0.f;
+        }
+    }
+    for (int p = prow; p < a.HW; p += pstep) {
+        const long long e = base + (long long)p * a.C;
+        const bf16x8 v = *(const bf16x8*)(a.x + e);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act);
+        if (a.mask) {
+            const unsigned m = a.mask[e >> 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (m >> j) & 1 ? o[j] * a.mask_scale : 0.f;
+        }
+        if (a.res) {
+            const bf16x8 r = *(const bf16x8*)(a.res + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += (float)r[j];
+        }
+        bf16x8 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (bf16)o[j];
+        *(bf16x8*)(a.y + e) = w;
+    }
+}
+
+// Backward.  With g = dy * mask * act'(z), xhat = (x - mean) rstd, m = cpg*HW:
+//   dgamma_c = sum g xhat,  dbeta_c = sum g,
+//   dx = rstd * ( gamma_c g - (S1 + xhat S2)/m ),  S1 = sum_group gamma g,  S2 = sum_group gamma g xhat.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
+    __shared__ float s_red[256];
+    __shared__ float s_s1[32], s_s2[32];
+    const int tid = threadIdx.x;
+    const int slabs = a.C / a.SC;
+    const int n = blockIdx.x / slabs, c0 = (blockIdx.x - n * slabs) * a.SC;
+    const int vps = a.SC / 8;
+    const int cv = tid % vps, prow = tid / vps, pstep = THREADS / vps;
+    const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
+    const int cpg = a.G > 0 ? a.C / a.G : 1;
+
+    float ga[8], be[8], mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cl = cv * 8 + j;
+        if (a.G > 0) {
+            const int g = (c0 + cl) / cpg;
+            ga[j] = a.gamma[c0 + cl]; be[j] = a.beta[c0 + cl];
+            mean[j] = a.stats[((long long)n * a.G + g) * 2 + 0];
+            rstd[j] = a.stats[((long long)n * a.G + g) * 2 + 1];
+        } else {
+            ga[j] = 1.f; be[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f;
+        }
+    }
+    float S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) S1[j] = S2[j] = 0.f;
+    if (a.G > 0) {
+        float a1[8], a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+        for (int p = prow; p < a.HW; p += pstep) {
+            const long long e = base + (long long)p * a.C;
+            const bf16x8 xv = *(const bf16x8*)(a.x + e);
+            const bf16x8 dv = *(const bf16x8*)(a.dy + e);
+            const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xv[j] - mean[j]) * rstd[j];
+                float g = (float)dv[j] * act_bwd(xh * ga[j] + be[j], a.act);
+                g = (m >> j) & 1 ? (a.mask ? g * a.mask_scale : g) : 0.f;
+                a1[j] += g; a2[j] += g * xh;
+            }
+        }
+        block_reduce_cols<THREADS>(a1, vps, s_red, tid);
+        block_reduce_cols<THREADS>(a2, vps, s_red, tid);
+        __syncthreads();
+        if (tid < vps) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cl = tid * 8 + j;
+                atomicAdd(a.dbeta + c0 + cl, a1[j]);
+                atomicAdd(a.dgamma + c0 + cl, a2[j]);
+                s_red[cl] = a1[j] * ga[j];
+                s_red[64 + cl] = a2[j] * ga[j];
+            }
+        }
+        __syncthreads();
+        const int ngrp = a.SC / cpg;
+        if (tid < ngrp) {
+            float u = 0.f, v = 0.f;
+            for (int c = 0; c < cpg; ++c) { u += s_red[tid * cpg + c]; v += s_red[64 + tid * cpg + c]; }
+            const float im = 1.0f / (float)(cpg * a.HW);
+            s_s1[tid] = u * im; s_s2[tid] = v * im;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (cv * 8 + j) / cpg;
+            S1[j] = s_s1[g]; S2[j] = s_s2[g];
+        }
+    }
+    float db[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) db[j] = 0.f;
+    for (int p = prow; p < a.HW; p += pstep) {
+        const long long e = base + (long long)p * a.C;
+        const bf16x8 xv = *(const bf16x8*)(a.x + e);
+        const bf16x8 dv = *(const bf16x8*)(a.dy + e);
+        const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+        bf16x8 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)xv[j] - mean[j]) * rstd[j];
+            float g = (float)dv[j] * act_bwd(xh * ga[j] + be[j], a.act);
+            g = (m >> j) & 1 ? (a.mask ? g * a.mask_scale : g) : 0.f;
+            const float dx = rstd[j] * (ga[j] * g - (S1[j] + xh * S2[j]));
+            db[j] += dx;
+            w[j] = (bf16)dx;
+        }
+        *(bf16x8*)(a.y + e) = w;
+    }
+    if (a.dbias) {
+        block_reduce_cols<THREADS>(db, vps, s_red, tid);
+        if (tid < vps) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(a.dbias + c0 + tid * 8 + j, db[j]);
+        }
+    }
+}
+
+static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
+    DDPM_REQUIRE(d && d->x && d->y, "%s: null pointer", what);
+    DDPM_REQUIRE(d->N > 0 && d->HW > 0 && d->C > 0 && d->C % 8 == 0, "%s: C (%d) must be a positive multiple of 8", what, d->C);
+    DDPM_REQUIRE(d->G >= 0 && (d->G == 0 || (d->C % d->G == 0 && (d->gamma && d->beta && d->stats))),
+                 "%s: groups %d must divide C %d (and gamma/beta/stats must be given)", what, d->G, d->C);
+    int sc = d->C < 64 ? d->C : 64;
+    while (d->C % sc) sc -= 8;
+    if (d->G > 0) {
+        const int cpg = d->C / d->G;
+        DDPM_REQUIRE(cpg <= 64 && (cpg >= 8 ? cpg % 8 == 0 : 8 % cpg == 0), "%s: unsupported channels per group %d", what, cpg);
+        DDPM_REQUIRE(sc % cpg == 0 && sc / cpg <= 32, "%s: slab %d not a multiple of the group width %d", what, sc, cpg);
+    }
+    DDPM_REQUIRE(sc == 8 || sc == 16 || sc == 32 || sc == 64, "%s: slab width %d must be 8/16/32/64", what, sc);
+    a.x = (const bf16*)d->x; a.gamma = d->gamma; a.beta = d->beta; a.res = (const bf16*)d->res; a.mask = d->mask;
+    a.mask_scale = d->mask_scale; a.y = (bf16*)d->y; a.stats = d->stats; a.dy = (const bf16*)d->dy; a.dgamma = d->dgamma;
+    a.dbeta = d->dbeta; a.dbias = d->dbias; a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.SC = sc; a.act = d->act;
+    a.eps = d->eps;
+    return DDPM_OK;
+}
+
+extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GnArgs a;
+    if (int rc = gn_prepare(a, d, "gn_forward")) return rc;
+    const int units = a.N * (a.C / a.SC);
+    const long long vecs = (long long)a.HW * (a.SC / 8);
+    if (vecs <= 128) hipLaunchKernelGGL(gn_fwd_kernel<64>, dim3(units), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(gn_fwd_kernel<256>, dim3(units), dim3(256), 0, stream, a);
+    return ddpm_check_launch("gn_forward");
+}
+
+extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GnArgs a;
+    if (int rc = gn_prepare(a, d, "gn_backward")) return rc;
+    DDPM_REQUIRE(d->dy, "gn_backward: null dy");
+    DDPM_REQUIRE(a.G == 0 || (a.dgamma && a.dbeta), "gn_backward: dgamma/dbeta required");
+    const int units = a.N * (a.C / a.SC);
+    const long long vecs = (long long)a.HW * (a.SC / 8);
+    if (vecs <= 128) hipLaunchKernelGGL(gn_bwd_kernel<64>, dim3(units), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(gn_bwd_kernel<256>, dim3(units), dim3(256), 0, stream, a);
+    return ddpm_check_launch("gn_backward");
+}

@@ -32,6 +32,23 @@ class ConvDesc(C.Structure):
     ]
 
 
+class GnDesc(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("gamma", _vp), ("beta", _vp), ("res", _vp), ("mask", _vp), ("mask_scale", _f),
+        ("y", _vp), ("stats", _vp), ("dy", _vp), ("dgamma", _vp), ("dbeta", _vp), ("dbias", _vp),
+        ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("kind", _i), ("N", _i), ("IH", _i), ("IW", _i),
+        ("in0", _vp), ("in1", _vp), ("C0", _i), ("C1", _i),
+        ("in_add", _vp), ("in_mask", _vp), ("in_mask_scale", _f),
+        ("dy", _vp), ("Cout", _i), ("dy_cs", _i), ("dw", _vp),
+    ]
+
+
 _PROTOS = {
     "ddpm_abi_version": ([], _i),
     "ddpm_q_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _u32, _vp], _i),
@@ -44,6 +61,14 @@ _PROTOS = {
     "ddpm_tanh_bwd_nchw_to_nhwc": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_bump_seed": ([_vp, _vp], _i),
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
+    "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
+    "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
+    "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
+    "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),
+    "ddpm_spatial_sum": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "ddpm_dropout_masks": ([_vp, _vp, _i, _i64, _f, _vp, _vp], _i),
 }
 
 _lib = None

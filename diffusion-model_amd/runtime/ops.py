@@ -46,3 +46,77 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      out_cs=(0 if f32_nchw else out.shape[3]), act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC))
     hip.call("ddpm_conv_forward", C.byref(d), hip.stream())
     return out
+
+
+def conv_wgrad(kind: int, x0: Tensor, dy: Tensor, cout: int, dw: Tensor, *, x1: Optional[Tensor] = None,
+               in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0) -> Tensor:
+    """dw (fp32 [slices][cout][C0+C1], kernel layout) += weight gradient.  x0/x1: the forward inputs; dy: NHWC bf16."""
+    n, ih, iw, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    assert dy.dtype == BF16 and dy.is_contiguous() and dw.dtype == torch.float32 and dw.is_contiguous()
+    assert dw.shape[1] == cout and dw.shape[2] == c0 + c1, (tuple(dw.shape), cout, c0, c1)
+    d = hip.WgradDesc(kind=kind, N=n, IH=ih, IW=iw, in0=hip.ptr(x0), in1=hip.ptr(x1), C0=c0, C1=c1, in_add=hip.ptr(in_add),
+                      in_mask=hip.ptr(in_mask), in_mask_scale=in_scale, dy=hip.ptr(dy), Cout=cout, dy_cs=dy.shape[3], dw=hip.ptr(dw))
+    hip.call("ddpm_conv_wgrad", C.byref(d), hip.stream())
+    return dw
+
+
+def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int, *,
+                   res: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
+                   stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5):
+    """x: NHWC bf16.  Returns (y, stats) with stats fp32 [N][G][2] (None when groups == 0)."""
+    n, h, w, c = x.shape
+    assert x.dtype == BF16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    if groups > 0 and stats is None:
+        stats = torch.empty(n, groups, 2, device=x.device, dtype=torch.float32)
+    d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
+                   y=hip.ptr(out), stats=hip.ptr(stats), dy=None, dgamma=None, dbeta=None, dbias=None, N=n, HW=h * w, C=c, G=groups,
+                   act=act, eps=eps)
+    hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream())
+    return out, stats
+
+
+def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int,
+                    stats: Optional[Tensor], dgamma: Optional[Tensor], dbeta: Optional[Tensor], *, dbias: Optional[Tensor] = None,
+                    mask: Optional[Tensor] = None, mask_scale: float = 1.0, out: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    n, h, w, c = x.shape
+    assert dy.shape == x.shape and dy.dtype == BF16 and dy.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=None, mask=hip.ptr(mask), mask_scale=mask_scale,
+                   y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), dgamma=hip.ptr(dgamma), dbeta=hip.ptr(dbeta),
+                   dbias=hip.ptr(dbias), N=n, HW=h * w, C=c, G=groups, act=act, eps=eps)
+    hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream())
+    return out
+
+
+def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """x: NHWC bf16; w9c: fp32 [9][C] tap-major."""
+    n, h, w, c = x.shape
+    assert x.dtype == BF16 and x.is_contiguous() and w9c.shape == (9, c) and w9c.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    hip.call("ddpm_dwconv3x3_forward", hip.ptr(x), hip.ptr(w9c), hip.ptr(bias), hip.ptr(out), n, h, w, c, hip.stream())
+    return out
+
+
+def dwconv3x3_wgrad(x: Tensor, dy: Tensor, dw9c: Tensor, db: Optional[Tensor]) -> None:
+    n, h, w, c = x.shape
+    assert dy.shape == x.shape and dw9c.shape == (9, c)
+    hip.call("ddpm_dwconv3x3_wgrad", hip.ptr(x), hip.ptr(dy), hip.ptr(dw9c), hip.ptr(db), n, h, w, c, hip.stream())
+
+
+def colsum(x: Tensor, out: Tensor, c: int) -> None:
+    """out[c] += sum over rows of NHWC bf16 x (any leading dims, last dim = channel stride)."""
+    cs = x.shape[-1]
+    hip.call("ddpm_colsum", hip.ptr(x), hip.ptr(out), x.numel() // cs, c, cs, hip.stream())
+
+
+def spatial_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty(n, c, device=x.device, dtype=torch.float32)
+    hip.call("ddpm_spatial_sum", hip.ptr(x), hip.ptr(out), n, h * w, c, hip.stream())
+    return out

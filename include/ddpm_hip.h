@@ -101,6 +101,66 @@ typedef struct ddpm_conv_desc {
 /* y = act(conv(x) + bias) [* mask] [+ res] for every kind above. */
 int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream);
 
+/* ---- GroupNorm + activation (+ dropout mask, + residual) on NHWC bf16 (groupnorm.hip) ------------- */
+
+typedef struct ddpm_gn_desc {
+    const void* x;            /* NHWC bf16 [N][HW][C]: the tensor being normalised (a convolution's raw output) */
+    const float* gamma;       /* fp32 [C] (GroupNorm.weight) */
+    const float* beta;        /* fp32 [C] (GroupNorm.bias) */
+    const void* res;          /* optional NHWC bf16 residual added last (conv_block.py:134-135) */
+    const uint8_t* mask;      /* optional dropout keep bits applied to the activated output (the NEXT conv's nn.Dropout) */
+    float mask_scale;
+    void* y;                  /* forward: output; backward: dx */
+    float* stats;             /* fp32 [N][G][2] = (mean, rstd): written by forward, read by backward */
+    const void* dy;           /* backward: gradient w.r.t. the output (before `res` was added) */
+    float* dgamma;            /* backward: fp32 [C], accumulated (+=) */
+    float* dbeta;             /* backward: fp32 [C], accumulated (+=) */
+    float* dbias;             /* backward, optional: fp32 [C] += sum of dx over n,h,w (bias gradient of the producing conv) */
+    int N, HW, C, G;          /* G = 0: no normalisation, activation only */
+    int act;
+    float eps;
+} ddpm_gn_desc;
+
+/* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:
+ * constituent_blocks.py:68-73,83-88,169-174,182-187; conv_block.py:67-72,90-95,110-114; unets.py:80-85,162-167 */
+int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream);
+/* dx, dgamma, dbeta (and dbias) of the above. */
+int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
+
+/* ---- depthwise 3x3 convolution, stride 1, padding 1, NHWC bf16 (dwconv.hip) ---------------------- */
+
+/* nn.Conv2d(C, C, 3, padding=1, groups=C) of conv_block.py:79-88.  w: fp32 [9][C] (tap-major), bias fp32 [C] or NULL.
+ * Also computes the data-gradient when given the tap-flipped weights and no bias. */
+int ddpm_dwconv3x3_forward(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
+                           ddpm_stream_t stream);
+/* dw[9][C] += sum dy * shifted x ; db[C] += sum dy   (fp32, accumulated with atomics; caller zeroes) */
+int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* db, int N, int H, int W, int C, ddpm_stream_t stream);
+
+/* ---- weight gradient of the dense convolutions (conv_wgrad.hip) ---------------------------------- */
+
+typedef struct ddpm_wgrad_desc {
+    int kind;                 /* forward kind: DDPM_CONV_3X3_S1 / _S2 / DDPM_CONV_1X1 / DDPM_CONVT_2X2_S2 */
+    int N, IH, IW;            /* dims of the forward INPUT tensor */
+    const void* in0; const void* in1; int C0, C1;      /* forward inputs, exactly as given to ddpm_conv_forward */
+    const float* in_add; const uint8_t* in_mask; float in_mask_scale;
+    const void* dy;           /* NHWC bf16 gradient of the forward output, channel stride dy_cs */
+    int Cout, dy_cs;
+    float* dw;                /* fp32 [slices][Cout][C0+C1], accumulated (+=) with atomics; caller zeroes */
+} ddpm_wgrad_desc;
+
+int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream);
+
+/* db[C] += column sums of an NHWC bf16 tensor [rows][cs] (first C channels); fp32 atomics. */
+int ddpm_colsum(const void* x, float* out, int64_t rows, int C, int cs, ddpm_stream_t stream);
+
+/* out[n][c] (+)= sum over pixels of x[n][p][c]: gradient of the broadcast time-embedding add (unets.py:128,237). fp32 [N][C]. */
+int ddpm_spatial_sum(const void* x, float* out, int N, int HW, int C, ddpm_stream_t stream);
+
+/* Fill dropout keep-bit masks: for each of `nsites` sites, bytes[offset_i .. offset_i + nbytes_i) get 8 Bernoulli(keep)
+ * bits each from Philox keyed by (*seed, site index).  offsets: device int64 [nsites+1] (prefix sums of bytes). */
+int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int nsites, int64_t total_bytes, float keep,
+                       const uint64_t* seed, ddpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

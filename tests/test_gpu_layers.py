@@ -1,0 +1,159 @@
+"""GPU parity of GroupNorm(+act/mask/residual) fwd/bwd, depthwise 3x3 fwd/dgrad/wgrad, dense weight-gradient
+and the small reductions, each against torch fp32 on CPU with identical bf16-rounded operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dm_amd.runtime import hip, ops, pack
+from oracle import ref_cpu as O
+from oracle.noise import hash_normal, hash_uniform
+from test_gpu_conv import assert_rel, nchw, nhwc, r16, torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(k):
+    return (k.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
+
+
+@pytest.mark.parametrize("n,c,h,g,act", [(2, 32, 16, 16, "gelu"), (3, 64, 8, 16, "silu"), (2, 128, 4, 16, "gelu"),
+                                          (5, 512, 2, 32, "gelu"), (2, 256, 2, 16, "none"), (2, 64, 32, 16, "gelu"),
+                                          (2, 32, 8, 0, "gelu")])
+def test_groupnorm_act_fwd_bwd(dev, n, c, h, g, act):
+    x = r16(hash_normal((n, c, h, h), 1) * 1.5 + 0.7)
+    gamma, beta = hash_normal((c,), 2) * 0.3 + 1, hash_normal((c,), 3) * 0.3
+    res = r16(hash_normal((n, c, h, h), 4))
+    keep = hash_uniform((n, h, h, c), 5) < 0.9
+    gy = r16(hash_normal((n, c, h, h), 6))
+    a = O.act_fn(act) if act != "none" else (lambda v: v)
+
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.group_norm(xr, g, gr, br, eps=1e-5) if g else xr
+    pre = a(z) * keep.permute(0, 3, 1, 2) / 0.9
+    ref = pre + res
+    grads = torch.autograd.grad(pre, [xr, gr, br] if g else [xr], gy)
+
+    y, stats = ops.gn_act_forward(nhwc(x, dev), gamma.to(dev) if g else None, beta.to(dev) if g else None, g, hip.ACT[act],
+                                  res=nhwc(res, dev), mask=bits(keep).to(dev), mask_scale=1 / 0.9)
+    assert_rel(nchw(y), ref)
+    if g:
+        xg = x.view(n, g, -1)
+        torch.testing.assert_close(stats[..., 0].cpu(), xg.mean(-1), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(stats[..., 1].cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-4)
+    dgam, dbet, dbias = (torch.zeros(c, device=dev) for _ in range(3))
+    dx = ops.gn_act_backward(nhwc(x, dev), nhwc(gy, dev), gamma.to(dev) if g else None, beta.to(dev) if g else None, g, hip.ACT[act],
+                             stats, dgam if g else None, dbet if g else None, dbias=dbias, mask=bits(keep).to(dev), mask_scale=1 / 0.9)
+    assert_rel(nchw(dx), grads[0], 1.5e-2)
+    assert_rel(dbias.cpu(), grads[0].sum((0, 2, 3)), 2e-2)
+    if g:
+        assert_rel(dgam.cpu(), grads[1], 1e-2)
+        assert_rel(dbet.cpu(), grads[2], 1e-2)
+
+
+@pytest.mark.parametrize("n,c,h,w_", [(2, 64, 16, 16), (3, 128, 8, 8), (5, 512, 2, 2), (1, 64, 5, 7), (2, 256, 4, 4)])
+def test_depthwise_fwd_dgrad_wgrad(dev, n, c, h, w_):
+    x = r16(hash_normal((n, c, h, w_), 1))
+    w = hash_normal((c, 1, 3, 3), 2) * 0.3
+    b = hash_normal((c,), 3) * 0.1
+    gy = r16(hash_normal((n, c, h, w_), 4))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, padding=1, groups=c)
+    gx, gw, gb = torch.autograd.grad(ref, [xr, wr, br], gy)
+    w9 = w.view(c, 9).t().contiguous().to(dev)
+    y = ops.dwconv3x3(nhwc(x, dev), w9, b.to(dev))
+    assert_rel(nchw(y), ref.detach())
+    w9f = w.flip(2, 3).reshape(c, 9).t().contiguous().to(dev)
+    dx = ops.dwconv3x3(nhwc(gy, dev), w9f, None)
+    assert_rel(nchw(dx), gx)
+    dw, db = torch.zeros(9, c, device=dev), torch.zeros(c, device=dev)
+    ops.dwconv3x3_wgrad(nhwc(x, dev), nhwc(gy, dev), dw, db)
+    assert_rel(dw.t().reshape(c, 1, 3, 3).cpu(), gw, 5e-3)
+    assert_rel(db.cpu(), gb, 5e-3)
+
+
+WG_CASES = [
+    (hip.CONV_3X3_S1, 2, 32, 32, 16, 16),
+    (hip.CONV_3X3_S1, 3, 64, 32, 8, 8),
+    (hip.CONV_3X3_S1, 5, 256, 512, 2, 2),
+    (hip.CONV_3X3_S1, 2, 16, 32, 32, 32),
+    (hip.CONV_3X3_S1, 2, 32, 3, 32, 32),
+    (hip.CONV_3X3_S1, 1, 32, 64, 12, 20),
+    (hip.CONV_3X3_S2, 2, 32, 64, 16, 16),
+    (hip.CONV_3X3_S2, 7, 128, 256, 4, 4),
+    (hip.CONV_1X1, 2, 32, 64, 16, 16),
+    (hip.CONV_1X1, 2, 512, 256, 2, 2),
+    (hip.CONV_1X1, 9, 32, 128, 1, 1),
+    (hip.CONV_1X1, 300, 64, 32, 8, 8),
+    (hip.CONVT_2X2_S2, 2, 64, 32, 8, 8),
+    (hip.CONVT_2X2_S2, 3, 256, 128, 2, 2),
+]
+
+
+def unpack_dw(kind, dwk, co, ci):
+    """kernel-layout fp32 [slices][co][ci_padded] -> torch layout"""
+    dwk = dwk[:, :, :ci]
+    if kind in (hip.CONV_3X3_S1, hip.CONV_3X3_S2):
+        return dwk.view(3, 3, co, ci).permute(2, 3, 0, 1)
+    if kind == hip.CONV_1X1:
+        return dwk.view(co, ci, 1, 1)
+    return dwk.view(2, 2, co, ci).permute(3, 2, 0, 1)
+
+
+@pytest.mark.parametrize("kind,n,ci,co,h,w_", WG_CASES)
+def test_conv_wgrad(dev, kind, n, ci, co, h, w_):
+    k = {hip.CONV_3X3_S1: 3, hip.CONV_3X3_S2: 3, hip.CONV_1X1: 1, hip.CONVT_2X2_S2: 2}[kind]
+    wshape = (ci, co, k, k) if kind == hip.CONVT_2X2_S2 else (co, ci, k, k)
+    w = torch.zeros(wshape, requires_grad=True)
+    x = r16(hash_normal((n, ci, h, w_), 3))
+    ref = torch_ref(kind, x, w, None)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    (gw,) = torch.autograd.grad(ref, w, gy)
+    slices = {3: 9, 1: 1, 2: 4}[k]
+    dwk = torch.zeros(slices, co, ci, device=dev)
+    ops.conv_wgrad(kind, nhwc(x, dev), nhwc(gy, dev, (co + 7) // 8 * 8), co, dwk)
+    assert_rel(unpack_dw(kind, dwk.cpu(), co, ci), gw, 5e-3)
+    # accumulation semantics: a second call adds
+    ops.conv_wgrad(kind, nhwc(x, dev), nhwc(gy, dev, (co + 7) // 8 * 8), co, dwk)
+    assert_rel(unpack_dw(kind, dwk.cpu(), co, ci), 2 * gw, 5e-3)
+
+
+def test_conv_wgrad_fused_input(dev):
+    n, c0, c1, co, h = 3, 64, 64, 64, 8
+    x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))
+    temb = hash_normal((n, c0), 3)
+    keep = hash_uniform((n, h, h, c0), 6) < 0.9
+    xin = torch.cat([r16(r16(x0 + temb[:, :, None, None]) * keep.permute(0, 3, 1, 2) / 0.9), x1], 1)
+    w = torch.zeros(co, c0 + c1, 3, 3, requires_grad=True)
+    ref = F.conv2d(xin, w, None, padding=1)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    (gw,) = torch.autograd.grad(ref, w, gy)
+    dwk = torch.zeros(9, co, c0 + c1, device=dev)
+    ops.conv_wgrad(hip.CONV_3X3_S1, nhwc(x0, dev), nhwc(gy, dev), co, dwk, x1=nhwc(x1, dev), in_add=temb.to(dev),
+                   in_mask=bits(keep).to(dev), in_scale=1 / 0.9)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, dwk.cpu(), co, c0 + c1), gw, 5e-3)
+
+
+def test_small_reductions_and_masks(dev):
+    x = r16(hash_normal((5, 7, 3, 32), 1))          # NHWC directly
+    out = torch.zeros(20, device=dev)
+    xd = x.to(dev).bfloat16()
+    ops.colsum(xd, out, 20)
+    assert_rel(out.cpu(), x.reshape(-1, 32).sum(0)[:20], 5e-3)
+    ss = ops.spatial_sum(xd)
+    assert_rel(ss.cpu(), x.sum((1, 2)), 5e-3)
+    # dropout masks: deterministic in the seed, right keep rate, independent across sites
+    sizes = [4096, 8192, 1000 * 4]
+    offs = torch.tensor([0, sizes[0], sizes[0] + sizes[1], sum(sizes)], device=dev, dtype=torch.long)
+    seed = torch.tensor([77], device=dev, dtype=torch.long)
+    m1 = torch.zeros(sum(sizes), device=dev, dtype=torch.uint8)
+    m2 = torch.zeros_like(m1)
+    hip.call("ddpm_dropout_masks", hip.ptr(m1), hip.ptr(offs), 3, sum(sizes), 0.9, hip.ptr(seed), hip.stream())
+    hip.call("ddpm_dropout_masks", hip.ptr(m2), hip.ptr(offs), 3, sum(sizes), 0.9, hip.ptr(seed), hip.stream())
+    assert torch.equal(m1, m2)
+    bitsum = sum(((m1 >> j) & 1).sum().item() for j in range(8))
+    assert abs(bitsum / (8 * sum(sizes)) - 0.9) < 0.01
+    assert not torch.equal(m1[:4096], m1[4096:8192])
+    hip.call("ddpm_bump_seed", hip.ptr(seed), hip.stream())
+    hip.call("ddpm_dropout_masks", hip.ptr(m2), hip.ptr(offs), 3, sum(sizes), 0.9, hip.ptr(seed), hip.stream())
+    assert not torch.equal(m1, m2)
