@@ -23,8 +23,9 @@ struct ConvArgs {
     float in_mask_scale;
     const bf16* w; const float* bias;
     void* out; const bf16* res; const unsigned char* out_mask; float out_mask_scale;
-    int Cout, CoutW, out_cs;         // real output channels; rows per weight slice; channel stride of out
+    int Cout, CoutW, out_cs, w_rows; // real output channels; rows computed; channel stride of out; rows per weight slice
     int act, out_mode;
+    float* sum_out;                  // optional fp32 [N][Cout] per-image sums of the activated output (atomics)
 };
 
 template <int WAVES, int NT>
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
             const int row = it >> 2, part = it & 3;
             if (part >= parts) continue;
             const int j = row / BN, co = row - j * BN;
-            const bf16* wp = a.w + ((long long)g.tap_slice[tap0 + j] * a.CoutW + co0 + co) * Cin + c0 + part * 8;
+            const bf16* wp = a.w + ((long long)g.tap_slice[tap0 + j] * a.w_rows + co0 + co) * Cin + c0 + part * 8;
             *(bf16x8*)(s_w + row * CONV_RS + part * 16) = *(const bf16x8*)wp;
         }
         __syncthreads();
@@ -132,6 +133,31 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
 
     // ---- epilogue
     const int offh = g.cls_off_h[cls], offw = g.cls_off_w[cls];
+    if (a.sum_out) {
+        // per-image spatial sums from the fp32 accumulators (before any rounding, mask or residual)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = co0 + nt * 32 + (lane & 31);
+            const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+            float run = 0.f;
+            int run_n = -1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ril = row / thw, rr = row - ril * thw;
+                const int rty = rr / g.TW, rtx = rr - rty * g.TW;
+                const int n = n0 + ril, py = oy + rty, px = ox + rtx;
+                const bool ok = n < g.N && py < g.GH && px < g.GW && py * g.SO + offh < g.OH && px * g.SO + offw < g.OW;
+                if (!ok) continue;
+                if (n != run_n) {
+                    if (run_n >= 0 && co < a.Cout) atomicAdd(a.sum_out + (long long)run_n * a.Cout + co, run);
+                    run = 0.f; run_n = n;
+                }
+                run += act_fwd(acc[nt][r] + b, a.act);
+            }
+            if (run_n >= 0 && co < a.Cout) atomicAdd(a.sum_out + (long long)run_n * a.Cout + co, run);
+        }
+    }
     if (a.out_mode == OUT_F32_NCHW) {
         // few output channels (the image head): scattered fp32 stores straight from the accumulators
         float* out = (float*)a.out;
@@ -219,6 +245,7 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: input channels must be multiples of 16 (32 when two sources are concatenated); got %d + %d", d->C0, d->C1);
     DDPM_REQUIRE(d->Cout > 0 && d->CoutW >= d->Cout && d->CoutW % 32 == 0, "conv: CoutW (%d) must be a multiple of 32 >= Cout (%d)",
                  d->CoutW, d->Cout);
+    DDPM_REQUIRE(d->w_rows >= d->CoutW, "conv: w_rows (%d) < CoutW (%d)", d->w_rows, d->CoutW);
     DDPM_REQUIRE(d->out_mode == OUT_F32_NCHW || (d->out_cs >= d->Cout && d->out_cs % 8 == 0),
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
@@ -244,7 +271,7 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = d->out; a.res = (const bf16*)d->res;
     a.out_mask = d->out_mask; a.out_mask_scale = d->out_mask_scale;
-    a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.act = d->act; a.out_mode = d->out_mode;
+    a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.out_mode = d->out_mode; a.sum_out = d->sum_out;
 
     const int npix = a.g.NB * a.g.PH * a.g.PW;
     const int bm = 32 * waves, bn = 32 * nt;

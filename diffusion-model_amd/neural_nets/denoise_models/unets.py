@@ -1,0 +1,191 @@
+"""BaseUNet: the denoiser backbone behind the reference's constructor and forward signature
+(neural_nets/denoise_models/unets.py:243-273 there), executed by the HIP engine.
+
+The module owns ordinary fp32 nn.Parameters with exactly the reference's 350 state_dict keys, shapes and
+registration order, so checkpoints, optimizers, EMA copies and DDP wrappers see the same object they would see
+with the reference class.  The sub-modules are plain parameter containers: all arithmetic happens in
+runtime/engine.py, entered through one autograd Function.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from ...runtime.engine import UNetEngine, UNetSpec
+from ...utils.initializers import get_initializer
+from ..activations import activation_code
+
+# how a parameter is initialised (reference: unets.py:93-97,196-203; constituent_blocks.py:108-115,210-217,321-324;
+# conv_block.py:121-129; torch defaults for everything not touched there)
+W_INIT, W_INIT_EMBED_DEC, ONES, ZEROS, LINEAR_BIAS_DEFAULT = range(5)
+
+
+class _Slot(nn.Module):
+    """Parameter container addressed by dotted paths ('layers.0.layers.1.expansion.1.weight')."""
+
+    def put(self, path: str, p: nn.Parameter) -> None:
+        head, _, rest = path.partition(".")
+        if not rest:
+            self.register_parameter(head, p)
+            return
+        if head not in self._modules:
+            self.add_module(head, _Slot())
+        self._modules[head].put(rest, p)
+
+
+def parameter_table(spec: UNetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """(name, shape, init rule) of every parameter in the reference's registration order."""
+    out: List[Tuple[str, Tuple[int, ...], int]] = []
+    st, te, ex = spec.stages, spec.t_dim, spec.expand
+
+    def conv(name, co, ci, k, bias_rule=ONES):
+        out.append((name + ".weight", (co, ci, k, k), W_INIT))
+        out.append((name + ".bias", (co,), bias_rule))
+
+    def norm(name, c):
+        out.append((name + ".weight", (c,), ONES))
+        out.append((name + ".bias", (c,), ZEROS))
+
+    def sir(pre, c):
+        e = int(ex * c)
+        conv(pre + "expansion.1", e, c, 1); norm(pre + "expansion.2", e)
+        conv(pre + "depthwise.1", e, 1, 3); norm(pre + "depthwise.2", e)
+        conv(pre + "projection.1", c, e, 1); norm(pre + "projection.2", c)
+
+    def embed(pre, c, rule):
+        out.append((pre + "layers.0.weight", (2 * c, te), rule))
+        out.append((pre + "layers.0.bias", (2 * c,), LINEAR_BIAS_DEFAULT))
+        out.append((pre + "layers.2.weight", (c, 2 * c), rule))
+        out.append((pre + "layers.2.bias", (c,), ONES))
+
+    e = "encoder."
+    conv(e + "stem_layers.0", st[0], spec.img_channels, 3)
+    ins = [st[0]] + st[:-1]
+    for i, (ci, co) in enumerate(zip(ins, st)):
+        b = f"{e}layers.{i}.layers."
+        conv(b + "0.0", co, ci, 3); norm(b + "0.1", co)
+        sir(b + "1.", co); sir(b + "2.", co)
+        conv(b + "3.0", co, co, 3); norm(b + "3.1", co)
+    for i, ci in enumerate(ins):
+        embed(f"{e}t_embeddings.{i}.", ci, W_INIT)
+    conv(e + "latent_layers.0", spec.latent_dim, st[-1], 3); norm(e + "latent_layers.1", spec.latent_dim)
+
+    d = "decoder."
+    rs = st[::-1]
+    conv(d + "decoder_input_layers.0", rs[0], spec.latent_dim, 3); norm(d + "decoder_input_layers.1", rs[0])
+    outs = rs[1:] + [rs[-1]]
+    for i, (ci, co) in enumerate(zip(rs, outs)):
+        b = f"{d}layers.{i}.layers."
+        conv(b + "0.0", ci, 2 * ci, 3); norm(b + "0.1", ci)
+        sir(b + "1.", ci)
+        out.append((b + "2.0.weight", (ci, co, 2, 2), W_INIT)); out.append((b + "2.0.bias", (co,), ONES)); norm(b + "2.1", co)
+        sir(b + "3.", co); sir(b + "4.", co)
+    for i, ci in enumerate(rs):
+        embed(f"{d}t_embeddings.{i}.", ci, W_INIT_EMBED_DEC)
+    conv(d + "out_layers.0", rs[-1], rs[-1], 3)
+    conv(d + "out_layers.2", spec.img_channels, rs[-1], 3, bias_rule=ZEROS)
+    return out
+
+
+class _UNetFn(torch.autograd.Function):
+    """One autograd node for the whole denoiser: forward runs the fused program, backward replays its tape."""
+
+    @staticmethod
+    def forward(ctx, module: "BaseUNet", record: bool, x: Tensor, time: Tensor, *flat_params: Tensor):
+        eng = module._get_engine()
+        params = dict(zip(module._param_names, flat_params))
+        ctx.set_materialize_grads(False)
+        out, tape = eng.forward(params, x, time, train=module.training, record=record, taps=module._taps)
+        ctx.tape, ctx.module = tape, module
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        module = ctx.module
+        if ctx.tape is None or dout is None:
+            return (None, None, None, None) + (None,) * len(module._param_names)
+        eng = module._get_engine()
+        params = dict(zip(module._param_names, [p for p in module.parameters()]))
+        grads = eng.backward(ctx.tape, dout, params)
+        ctx.tape = None
+        return (None, None, None, None) + tuple(grads[k] for k in module._param_names)
+
+
+class BaseUNet(nn.Module):
+    """Drop-in for the reference BaseUNet: `BaseUNet(**kwargs)(input (N,C,H,W) float, time (N,) long) -> (N,C,H,W)`.
+
+    Keyword arguments are the ones the reference forwards (DDPM.yaml + CLI extras, unknown ones are accepted and
+    ignored, dm_utils.py:39-58 there).  `T` is NOT forwarded by the reference's DDPM wrapper, so the time
+    normaliser defaults to 100 exactly as it does there."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        act_name = kwargs.get("activation", "gelu")
+        activation_code(act_name)
+        self.spec = UNetSpec(
+            img_channels=kwargs["img_channels"], stages_channels=kwargs["stages_channels"], latent_dim=kwargs["latent_dim"],
+            expand_factor=kwargs.get("expand_factor", 4), drop_p=float(kwargs.get("drop_p", 0.1)),
+            t_embed_dim=kwargs.get("t_embed_dim", 32), activation=act_name, base_groups_norm=kwargs["base_groups_norm"],
+            time_norm=float(kwargs.get("T", 100)))
+        self.is_conditional = bool(kwargs.get("is_conditional", False))
+        device, dtype = kwargs.get("device", None), kwargs.get("dtype", None)
+        if dtype not in (None, torch.float32):
+            raise ValueError("parameters are kept in fp32 (the kernels compute in bf16 with fp32 accumulation)")
+        init_w = get_initializer(kwargs.get("initializer", "normal"))
+        init_dec_embed = get_initializer("he_uniform")
+        self.encoder, self.decoder = _Slot(), _Slot()
+        names = []
+        for name, shape, rule in parameter_table(self.spec):
+            t = torch.empty(shape, device=device, dtype=torch.float32)
+            if rule == W_INIT:
+                init_w(t)
+            elif rule == W_INIT_EMBED_DEC:
+                init_dec_embed(t)
+            elif rule == ONES:
+                nn.init.ones_(t)
+            elif rule == ZEROS:
+                nn.init.zeros_(t)
+            else:                                   # nn.Linear's default bias init: U(+-1/sqrt(fan_in))
+                bound = 1.0 / math.sqrt(self.spec.t_dim)
+                nn.init.uniform_(t, -bound, bound)
+            top, _, rest = name.partition(".")
+            getattr(self, top).put(rest, nn.Parameter(t))
+            names.append(name)
+        self._param_names: List[str] = names
+        self._engine = None
+        self._taps = None
+
+    # the engine holds device caches only; it is rebuilt on demand (after deepcopy / .to() / unpickling)
+    def _get_engine(self) -> UNetEngine:
+        if self._engine is None:
+            self._engine = UNetEngine(self.spec)
+        return self._engine
+
+    def __deepcopy__(self, memo):
+        eng, self._engine = self._engine, None
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            import copy
+            for k, v in self.__dict__.items():
+                setattr(new, k, copy.deepcopy(v, memo))
+        finally:
+            self._engine = eng
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        return st
+
+    def forward(self, input: Tensor, time: Tensor, *args, **kwargs) -> Tensor:
+        if not input.is_cuda:
+            raise RuntimeError("BaseUNet runs on the HIP kernels only: move the module and its inputs to an MI355X (cuda) device")
+        params = [p for p in self.parameters()]
+        # grad mode is off inside Function.forward, so decide here whether the tape must be recorded
+        record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _UNetFn.apply(self, record, input.float(), time, *params)

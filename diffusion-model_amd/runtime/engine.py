@@ -1,0 +1,441 @@
+"""Host-side executor of the UNet denoiser on the HIP kernels.
+
+The reference expresses the network as a tree of nn.Modules that autograd differentiates op by op
+(unets.py:100-132,206-240; constituent_blocks.py:135-147,227-243; conv_block.py:132-136).  Here the same
+arithmetic is a straight-line program of fused kernels driven from Python:
+
+    conv (MFMA implicit GEMM; concat / time-embedding add / input dropout fused into its loader)
+      -> GroupNorm + activation (+ output dropout mask, + residual) in one pass
+    depthwise 3x3 stencil -> GroupNorm + activation
+
+Every forward op records a closure on a tape; `backward` replays the tape in reverse.  Gradients of tensors
+with two consumers (skip connections, residual inputs) are summed inside the later data-gradient kernel's
+epilogue, so no separate accumulation pass exists.  Activations are NHWC bf16, statistics and parameter
+gradients fp32.  The parameters themselves stay fp32 in torch layout; bf16 kernel-layout copies are cached
+and refreshed when a parameter's version counter changes.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import hip, ops, pack
+
+BF16 = torch.bfloat16
+K33, K33S2, K11, KT22 = hip.CONV_3X3_S1, hip.CONV_3X3_S2, hip.CONV_1X1, hip.CONVT_2X2_S2
+
+
+class Var:
+    """An activation and (during backward) the gradient flowing into it."""
+    __slots__ = ("v", "g", "need_grad")
+
+    def __init__(self, v: Tensor, need_grad: bool = True):
+        self.v = v
+        self.g: Optional[Tensor] = None
+        self.need_grad = need_grad
+
+
+class UNetSpec:
+    """Static description of the denoiser: which parameters exist, their kinds and shapes.
+    Mirrors the constructor keywords the reference forwards to BaseUNet (dm_utils.py:39-58)."""
+
+    def __init__(self, img_channels: int, stages_channels: Sequence[int], latent_dim: int, expand_factor: int = 2,
+                 drop_p: float = 0.1, t_embed_dim: int = 32, activation: str = "gelu", base_groups_norm: int = 4,
+                 time_norm: float = 100.0):
+        self.img_channels = int(img_channels)
+        self.stages = [int(c) for c in stages_channels]
+        self.latent_dim = int(latent_dim)
+        self.expand = expand_factor
+        self.drop_p = float(drop_p)
+        self.t_dim = int(t_embed_dim)
+        self.act = hip.ACT[activation]
+        self.groups = 4 * int(base_groups_norm)
+        self.latent_groups = 8 * int(base_groups_norm)
+        self.time_norm = float(time_norm)
+        for c in self.stages + [self.latent_dim]:
+            if c % 32:
+                raise ValueError(f"stage/latent channel counts must be multiples of 32 for the MFMA kernels, got {c}")
+        if self.t_dim % 32:
+            raise ValueError(f"t_embed_dim must be a multiple of 32, got {self.t_dim}")
+        # (name, kind) of every convolution weight, for packing
+        self.convs: Dict[str, int] = {}
+        self.dwconvs: List[str] = []
+        self._enumerate()
+
+    def _sir(self, pre: str):
+        self.convs[pre + "expansion.1"] = K11
+        self.dwconvs.append(pre + "depthwise.1")
+        self.convs[pre + "projection.1"] = K11
+
+    def _enumerate(self):
+        n = len(self.stages)
+        e, d = "encoder.", "decoder."
+        self.convs[e + "stem_layers.0"] = K33
+        for i in range(n):
+            b = f"{e}layers.{i}.layers."
+            self.convs[b + "0.0"] = K33S2
+            self._sir(b + "1.")
+            self._sir(b + "2.")
+            self.convs[b + "3.0"] = K33
+            self.convs[f"{e}t_embeddings.{i}.layers.0"] = K11
+            self.convs[f"{e}t_embeddings.{i}.layers.2"] = K11
+        self.convs[e + "latent_layers.0"] = K33
+        self.convs[d + "decoder_input_layers.0"] = K33
+        for i in range(n):
+            b = f"{d}layers.{i}.layers."
+            self.convs[b + "0.0"] = K33
+            self._sir(b + "1.")
+            self.convs[b + "2.0"] = KT22
+            self._sir(b + "3.")
+            self._sir(b + "4.")
+            self.convs[f"{d}t_embeddings.{i}.layers.0"] = K11
+            self.convs[f"{d}t_embeddings.{i}.layers.2"] = K11
+        self.convs[d + "out_layers.0"] = K33
+        self.convs[d + "out_layers.2"] = K33
+
+
+def _as4d(kind: int, w: Tensor) -> Tensor:
+    return w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)     # nn.Linear weight -> 1x1 conv
+
+
+class WeightCache:
+    """bf16 kernel-layout copies of the convolution weights (forward and data-gradient forms)."""
+
+    def __init__(self, spec: UNetSpec):
+        self.spec = spec
+        self.fwd: Dict[str, Tensor] = {}
+        self.dgrad: Dict[str, Tensor] = {}
+        self.dw: Dict[str, Tensor] = {}
+        self.dw_flip: Dict[str, Tensor] = {}
+        self._ver: Dict[str, Tuple[int, int]] = {}
+
+    def refresh(self, params: Dict[str, Tensor], need_dgrad: bool, force: bool = False) -> None:
+        if force:
+            self._ver.clear()
+        for name, kind in self.spec.convs.items():
+            w = params[name + ".weight"]
+            key = (w.data_ptr(), w._version)
+            if self._ver.get(name) != key or (need_dgrad and name not in self.dgrad):
+                w4 = _as4d(kind, w.detach())
+                self.fwd[name] = pack.pack_fwd(kind, w4)
+                if need_dgrad:
+                    self.dgrad[name] = pack.pack_dgrad(kind, w4)
+                else:
+                    self.dgrad.pop(name, None)
+                self._ver[name] = key
+        for name in self.spec.dwconvs:
+            w = params[name + ".weight"]
+            key = (w.data_ptr(), w._version)
+            if self._ver.get(name) != key:
+                c = w.shape[0]
+                wd = w.detach()
+                self.dw[name] = wd.reshape(c, 9).t().contiguous()
+                self.dw_flip[name] = wd.flip(2, 3).reshape(c, 9).t().contiguous()
+                self._ver[name] = key
+
+
+class GradStore:
+    """fp32 gradient accumulators in kernel layout, carved from one flat zero-initialised buffer."""
+
+    def __init__(self, spec: UNetSpec, params: Dict[str, Tensor], device):
+        self.spec = spec
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, p in params.items():
+            base = name.rsplit(".", 1)[0]
+            if name.endswith(".weight") and base in spec.convs:
+                kind = spec.convs[base]
+                w4 = _as4d(kind, p)
+                if kind == KT22:
+                    ci, co = w4.shape[:2]
+                    shp = (4, co, ci)
+                else:
+                    co, ci = w4.shape[:2]
+                    shp = (w4.shape[2] * w4.shape[3], co, (ci + 15) // 16 * 16)
+            elif name.endswith(".weight") and base in spec.dwconvs:
+                shp = (9, p.shape[0])
+            else:
+                shp = tuple(p.shape)
+            n = 1
+            for s in shp:
+                n *= s
+            self.layout[name] = (off, shp)
+            off += (n + 3) // 4 * 4
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.views = {k: self.flat[o:o + _numel(s)].view(s) for k, (o, s) in self.layout.items()}
+
+    def zero(self):
+        self.flat.zero_()
+
+    def __getitem__(self, name: str) -> Tensor:
+        return self.views[name]
+
+    def to_torch_layout(self, name: str, like: Tensor) -> Tensor:
+        """Gradient of parameter `name` in the parameter's own (torch) layout, a fresh tensor."""
+        g = self.views[name]
+        base = name.rsplit(".", 1)[0]
+        if name.endswith(".weight") and base in self.spec.convs:
+            kind = self.spec.convs[base]
+            if kind == KT22:                                   # [a*2+b][co][ci] -> (ci, co, a, b)
+                ci, co = like.shape[:2]
+                return g.view(2, 2, co, ci).permute(3, 2, 0, 1).contiguous()
+            if like.dim() == 2:                                # nn.Linear
+                return g[0, :, :like.shape[1]].clone()
+            co, ci, kh, kw = like.shape
+            return g[:, :, :ci].reshape(kh, kw, co, ci).permute(2, 3, 0, 1).contiguous()
+        if name.endswith(".weight") and base in self.spec.dwconvs:
+            c = like.shape[0]
+            return g.t().reshape(c, 1, 3, 3).contiguous()
+        return g.clone()
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class UNetEngine:
+    """Runs BaseUNet.forward / its backward on the HIP kernels for one device."""
+
+    def __init__(self, spec: UNetSpec):
+        self.spec = spec
+        self.wc = WeightCache(spec)
+        self.grads: Optional[GradStore] = None
+        self.seed: Optional[Tensor] = None
+        self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
+        self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _site_sizes(self, n: int, h: int, w: int) -> List[int]:
+        """Element count of every dropout site in call order: for each inverted-residual block the block input,
+        the expansion output and the depthwise output (conv_block.py:57-58,77-78,100-101)."""
+        sp = self.spec
+        sizes: List[int] = []
+
+        def sir(c, hh, ww):
+            e = int(sp.expand * c)
+            sizes.extend([n * hh * ww * c, n * hh * ww * e, n * hh * ww * e])
+
+        hh, ww = h, w
+        for c in sp.stages:
+            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+            sir(c, hh, ww); sir(c, hh, ww)
+        rs = sp.stages[::-1]
+        outs = rs[1:] + [rs[-1]]
+        for ci, co in zip(rs, outs):
+            sir(ci, hh, ww)
+            hh, ww = 2 * hh, 2 * ww
+            sir(co, hh, ww); sir(co, hh, ww)
+        return sizes
+
+    def _make_masks(self, n: int, h: int, w: int, device) -> List[Tensor]:
+        key = (n, h, w)
+        if key not in self._mask_offsets:
+            sizes = self._site_sizes(n, h, w)
+            nbytes = [(s // 8 + 3) // 4 * 4 for s in sizes]
+            offs = [0]
+            for b in nbytes:
+                offs.append(offs[-1] + b)
+            self._mask_offsets[key] = (torch.tensor(offs, device=device, dtype=torch.long), offs, len(sizes))
+        offs_dev, offs, nsites = self._mask_offsets[key]
+        buf = torch.empty(offs[-1], device=device, dtype=torch.uint8)
+        if self.seed is None:
+            self.seed = torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.long)
+        hip.call("ddpm_bump_seed", hip.ptr(self.seed), hip.stream())
+        hip.call("ddpm_dropout_masks", hip.ptr(buf), hip.ptr(offs_dev), nsites, offs[-1], 1.0 - self.spec.drop_p, hip.ptr(self.seed),
+                 hip.stream())
+        return [buf[offs[i]:offs[i + 1]] for i in range(nsites)]
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, params: Dict[str, Tensor], x: Tensor, t: Tensor, train: bool, record: bool,
+                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None):
+        """x: NCHW fp32 on the GPU, t: int64 [N].  Returns (out NCHW fp32, tape or None).
+        train enables dropout; record keeps what backward needs."""
+        sp = self.spec
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == sp.img_channels
+        x = x.contiguous()
+        t = t.to(torch.long).contiguous()
+        n, c_img, h, w = x.shape
+        nst = len(sp.stages)
+        if h % (1 << nst) or w % (1 << nst):
+            raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
+        dev = x.device
+        self.wc.refresh(params, need_dgrad=record, force=self.always_repack)
+        if record:
+            if self.grads is None or self.grads.flat.device != dev:
+                self.grads = GradStore(sp, params, dev)
+        tape: Optional[List[Callable[[], None]]] = [] if record else None
+        use_drop = train and sp.drop_p > 0.0
+        if use_drop and masks is None:
+            masks = self._make_masks(n, h, w, dev)
+        mscale = 1.0 / (1.0 - sp.drop_p) if use_drop else 1.0
+        site = [0]
+        P = params
+        G = self.grads
+        wc = self.wc
+
+        def next_mask():
+            if not use_drop:
+                return None
+            m = masks[site[0]]
+            site[0] += 1
+            return m
+
+        def tap(name: str, v: Tensor):
+            if taps is not None:
+                taps[name] = v
+
+        # ---- fused units ------------------------------------------------------------------------
+        def conv_unit(name: str, x0: Var, *, x1: Optional[Var] = None, in_add: Optional[Var] = None, in_mask=None,
+                      norm: Optional[str] = None, groups: int = 0, act: int = 0, res: Optional[Var] = None, out_mask=None) -> Var:
+            """conv [-> GroupNorm] -> act [-> * out_mask] [+ res].  `norm` = parameter prefix of the GroupNorm."""
+            kind = sp.convs[name]
+            wf = wc.fwd[name]
+            bias = P[name + ".bias"]
+            cout = bias.shape[0]
+            raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
+                                   in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
+            gamma = P[norm + ".weight"] if norm else None
+            beta = P[norm + ".bias"] if norm else None
+            y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
+                                          mask=out_mask, mask_scale=mscale)
+            out = Var(y)
+            if tape is not None:
+                def bwd():
+                    dy = out.g
+                    if res is not None:                       # residual input receives the same gradient (no copy)
+                        assert res.g is None
+                        res.g = dy
+                    draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
+                                               G[norm + ".weight"] if norm else None, G[norm + ".bias"] if norm else None,
+                                               dbias=G[name + ".bias"], mask=out_mask, mask_scale=mscale)
+                    out.g = None
+                    ops.conv_wgrad(kind, x0.v, draw, cout, G[name + ".weight"], x1=None if x1 is None else x1.v,
+                                   in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
+                    if not x0.need_grad:
+                        return                                  # network inputs (image, sinusoid) need no gradient
+                    wd = wc.dgrad[name]
+                    c0 = x0.v.shape[3]
+                    dk = pack.DGRAD_KIND[kind]
+                    # gradient of the broadcast add = per-image spatial sum of this conv's own data-gradient,
+                    # accumulated in fp32 inside the kernel (x0.g, added afterwards, belongs to other consumers)
+                    dsum = torch.zeros(n, c0, device=dev, dtype=torch.float32) if in_add is not None else None
+                    x0.g = ops.conv_forward(dk, draw, wd, None, c0, res=x0.g, out_mask=in_mask, out_scale=mscale, rows=c0, sum_out=dsum)
+                    if in_add is not None:
+                        in_add.g = dsum
+                    if x1 is not None:
+                        c1 = x1.v.shape[3]
+                        x1.g = ops.conv_forward(dk, draw, wd, None, c1, res=x1.g, row0=c0, rows=c1)
+                tape.append(bwd)
+            return out
+
+        def dw_unit(pre: str, xin: Var, out_mask) -> Var:
+            """depthwise 3x3 -> GroupNorm -> act [-> * out_mask]   (conv_block.py:77-96)"""
+            name, norm = pre + "depthwise.1", pre + "depthwise.2"
+            raw = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"])
+            gamma, beta = P[norm + ".weight"], P[norm + ".bias"]
+            y, stats = ops.gn_act_forward(raw, gamma, beta, sp.groups, sp.act, mask=out_mask, mask_scale=mscale)
+            out = Var(y)
+            if tape is not None:
+                def bwd():
+                    draw = ops.gn_act_backward(raw, out.g, gamma, beta, sp.groups, sp.act, stats, G[norm + ".weight"], G[norm + ".bias"],
+                                               mask=out_mask, mask_scale=mscale)
+                    out.g = None
+                    ops.dwconv3x3_wgrad(xin.v, draw, G[name + ".weight"], G[name + ".bias"])
+                    assert xin.g is None
+                    xin.g = ops.dwconv3x3(draw, wc.dw_flip[name], None)
+                tape.append(bwd)
+            return out
+
+        def sir(pre: str, xin: Var) -> Var:
+            """SeparableInvertResidual (conv_block.py:132-136).  The three nn.Dropout sites act on the block input
+            (fused into the expansion conv's loader) and on the two intermediate activations (fused into the
+            GroupNorm epilogue that produces them)."""
+            m_in, m_e, m_d = next_mask(), next_mask(), next_mask()
+            e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
+            d = dw_unit(pre, e, m_d)
+            return conv_unit(pre + "projection.1", d, norm=pre + "projection.2", groups=sp.groups, act=0, res=xin)
+
+        def embed(pre: str, sin: Var) -> Var:
+            """EmbedBlock: Linear -> act -> Linear, as two 1x1 convolutions on a 1x1 'image' (constituent_blocks.py:308-328).
+            Result: fp32 [N][C] (the layout the conv loader's broadcast add reads)."""
+            h0 = conv_unit(pre + "layers.0", sin, act=sp.act)
+            name = pre + "layers.2"
+            bias = P[name + ".bias"]
+            c = bias.shape[0]
+            o = ops.conv_forward(K11, h0.v, wc.fwd[name], bias, c, f32_nchw=True)        # [N][C][1][1] fp32
+            out = Var(o.view(n, c))
+            if tape is not None:
+                def bwd():
+                    d = out.g.to(BF16).view(n, 1, 1, c)
+                    ops.colsum(d, G[name + ".bias"], c)
+                    ops.conv_wgrad(K11, h0.v, d, c, G[name + ".weight"])
+                    h0.g = ops.conv_forward(K11, d, wc.dgrad[name], None, h0.v.shape[3])
+                tape.append(bwd)
+            return out
+
+        # ---- the network ------------------------------------------------------------------------
+        xin = torch.empty(n, h, w, 16, device=dev, dtype=BF16)
+        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(xin), n, c_img, h * w, 16, hip.stream())
+        sin = torch.empty(n, 1, 1, sp.t_dim, device=dev, dtype=BF16)
+        hip.call("ddpm_time_embedding", hip.ptr(t), sp.time_norm, sp.t_dim, hip.ptr(sin), n, hip.stream())
+        sin_v = Var(sin, need_grad=False)
+
+        e, d = "encoder.", "decoder."
+        z = conv_unit(e + "stem_layers.0", Var(xin, need_grad=False), act=sp.act)
+        tap("enc.stem", z.v)
+        skips: List[Var] = []
+        for i in range(nst):
+            b = f"{e}layers.{i}.layers."
+            temb = embed(f"{e}t_embeddings.{i}.", sin_v)
+            a = conv_unit(b + "0.0", z, in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
+            a = sir(b + "1.", a)
+            a = sir(b + "2.", a)
+            z = conv_unit(b + "3.0", a, norm=b + "3.1", groups=sp.groups, act=sp.act)
+            skips.append(z)
+            tap(f"enc.stage{i}", z.v)
+        z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
+        tap("enc.latent", z.v)
+        z = conv_unit(d + "decoder_input_layers.0", z, norm=d + "decoder_input_layers.1", groups=sp.groups, act=sp.act)
+        tap("dec.input", z.v)
+        for i in range(nst):
+            b = f"{d}layers.{i}.layers."
+            temb = embed(f"{d}t_embeddings.{i}.", sin_v)
+            a = conv_unit(b + "0.0", z, x1=skips[nst - 1 - i], in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
+            a = sir(b + "1.", a)
+            a = conv_unit(b + "2.0", a, norm=b + "2.1", groups=sp.groups, act=sp.act)
+            a = sir(b + "3.", a)
+            z = sir(b + "4.", a)
+            tap(f"dec.stage{i}", z.v)
+        hfeat = conv_unit(d + "out_layers.0", z, act=sp.act)
+        name = d + "out_layers.2"
+        bias = P[name + ".bias"]
+        out = ops.conv_forward(K33, hfeat.v, wc.fwd[name], bias, c_img, act=hip.ACT["tanh"], f32_nchw=True)
+        if tape is not None:
+            out_holder = Var(out)
+
+            def bwd_head():
+                dz = torch.empty(n, h, w, 16, device=dev, dtype=BF16)
+                dy = out_holder.g.contiguous()
+                hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, 16, hip.stream())
+                ops.colsum(dz, G[name + ".bias"], c_img)
+                ops.conv_wgrad(K33, hfeat.v, dz, c_img, G[name + ".weight"])
+                hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
+            tape.append(bwd_head)
+            return out, (tape, out_holder)
+        return out, None
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """Replay the tape in reverse; returns {parameter name: fp32 gradient in torch layout}."""
+        tape, out_holder = ctx
+        self.grads.zero()
+        out_holder.g = dout
+        for fn in reversed(tape):
+            fn()
+        tape.clear()
+        return {k: self.grads.to_torch_layout(k, p) for k, p in params.items()}

@@ -27,8 +27,8 @@ class ConvDesc(C.Structure):
         ("in_add", _vp), ("in_mask", _vp), ("in_mask_scale", _f),
         ("w", _vp), ("bias", _vp),
         ("out", _vp), ("res", _vp), ("out_mask", _vp), ("out_mask_scale", _f),
-        ("Cout", _i), ("CoutW", _i), ("out_cs", _i),
-        ("act", _i), ("out_mode", _i),
+        ("Cout", _i), ("CoutW", _i), ("out_cs", _i), ("w_rows", _i),
+        ("act", _i), ("out_mode", _i), ("sum_out", _vp),
     ]
 
 

@@ -27,9 +27,11 @@ def conv_out_hw(kind: int, ih: int, iw: int):
 def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout: int, *, x1: Optional[Tensor] = None,
                  in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0, act: int = 0,
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
-                 out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None) -> Tensor:
+                 out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
+                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None) -> Tensor:
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
-    (or NCHW fp32 [N,cout,OH,OW] when f32_nchw)."""
+    (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
+    sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res."""
     n, ih, iw, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     assert x0.dtype == BF16 and x0.is_contiguous() and w.dtype == BF16 and w.is_contiguous()
@@ -41,9 +43,11 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
         else:
             out = torch.empty(n, oh, ow, out_cs or cout, device=x0.device, dtype=BF16)
     d = hip.ConvDesc(kind=kind, N=n, IH=ih, IW=iw, in0=hip.ptr(x0), in1=hip.ptr(x1), C0=c0, C1=c1, in_add=hip.ptr(in_add),
-                     in_mask=hip.ptr(in_mask), in_mask_scale=in_scale, w=hip.ptr(w), bias=hip.ptr(bias), out=hip.ptr(out),
-                     res=hip.ptr(res), out_mask=hip.ptr(out_mask), out_mask_scale=out_scale, Cout=cout, CoutW=w.shape[1],
-                     out_cs=(0 if f32_nchw else out.shape[3]), act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC))
+                     in_mask=hip.ptr(in_mask), in_mask_scale=in_scale, w=w.data_ptr() + row0 * w.shape[2] * 2, bias=hip.ptr(bias), out=hip.ptr(out),
+                     res=hip.ptr(res), out_mask=hip.ptr(out_mask), out_mask_scale=out_scale, Cout=cout,
+                     CoutW=(w.shape[1] if rows is None else (rows + 31) // 32 * 32), out_cs=(0 if f32_nchw else out.shape[3]),
+                     w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
+                     sum_out=hip.ptr(sum_out))
     hip.call("ddpm_conv_forward", C.byref(d), hip.stream())
     return out
 

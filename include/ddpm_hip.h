@@ -88,14 +88,19 @@ typedef struct ddpm_conv_desc {
     const float* in_add;       /* optional fp32 [N][C0] broadcast-added to in0 before the conv (Z + temb, unets.py:128,237) */
     const uint8_t* in_mask;    /* optional dropout keep bits for in0, 1 byte per 8 elements (conv_block.py:58) */
     float in_mask_scale;       /* 1/(1-p) */
-    const void* w;             /* bf16 [slices][CoutW][C0+C1], see ddpm_pack_* */
+    const void* w;             /* bf16 [slices][w_rows][C0+C1]; rows [0, CoutW) of every slice are used (point w at a later row
+                                * to compute a sub-range of output channels) */
     const float* bias;         /* fp32 [Cout] or NULL */
     void* out;                 /* NHWC bf16 with channel stride out_cs, or NCHW fp32 (out_mode) */
     const void* res;           /* optional NHWC bf16 tensor added in the epilogue (same layout as out) */
     const uint8_t* out_mask;   /* optional dropout keep bits applied to the result before `res` is added */
     float out_mask_scale;
-    int Cout, CoutW, out_cs;
+    int Cout, CoutW, out_cs;   /* real output channels written; rows computed (multiple of 32, >= Cout); channel stride of out */
+    int w_rows;                /* rows per weight slice (>= CoutW) */
     int act, out_mode;
+    float* sum_out;            /* optional fp32 [N][Cout] += per-image sum over output pixels of act(conv + bias), taken from the
+                                * fp32 accumulators before mask / res: with a data-gradient kind this is the gradient of the
+                                * broadcast time-embedding add (unets.py:128,237).  Caller zeroes it. */
 } ddpm_conv_desc;
 
 /* y = act(conv(x) + bias) [* mask] [+ res] for every kind above. */

@@ -54,7 +54,7 @@ def yaml_cfg():
         return yaml.safe_load(f)
 
 
-def build_ddpm(img_channels=3, activation="gelu", drop_p=0.0, stages=None, latent=None, seed=1):
+def build_ddpm(img_channels=3, activation="gelu", drop_p=0.0, stages=None, latent=None, seed=1, head_gain=1.0):
     y = yaml_cfg()
     kw = dict(y["DENOISE_MODEL_CONFIGS"])
     kw["activation"] = activation
@@ -67,7 +67,7 @@ def build_ddpm(img_channels=3, activation="gelu", drop_p=0.0, stages=None, laten
     cfg = O.UNetCfg(img_channels=img_channels, stages_channels=tuple(kw["stages_channels"]), latent_dim=latent,
                     expand_factor=kw["expand_factor"], drop_p=drop_p, t_embed_dim=kw["t_embed_dim"],
                     activation=activation, base_groups_norm=kw["base_groups_norm"])
-    params = O.hash_params(cfg, seed=seed)
+    params = O.hash_params(cfg, seed=seed, head_gain=head_gain)
     missing = m.load_state_dict(params, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     assert list(m.state_dict().keys()) == list(params.keys()), "key order differs from reference registration order"
@@ -252,7 +252,7 @@ def gen_unet_full():
 
 
 def gen_sample_chain():
-    m, cfg, params = build_ddpm(img_channels=3, activation="gelu")
+    m, cfg, params = build_ddpm(img_channels=3, activation="gelu", head_gain=0.3)
     m.eval()
     snaps = {}
     orig = m.reverse_q
@@ -276,7 +276,7 @@ def gen_sample_chain():
     finally:
         ref_ddpm.to_image = old_to_image
     final = torch.stack(imgs)
-    save("sample_chain.pt", {"N": 2, "shape": (32, 32), "noise_seed_base": 5000, "snapshots": snaps,
+    save("sample_chain.pt", {"head_gain": 0.3, "N": 2, "shape": (32, 32), "noise_seed_base": 5000, "snapshots": snaps,
                              "final_unit": final, "note": "call k of randn/randn_like uses hash_normal(shape, 5000+k); k=1 is X_T"})
 
 
