@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDPM hot path on MI355X (contract: python bench.py --gpus N --steps K --warmup W).
+
+A step = one training step of the denoiser on one synthetic batch already resident in HBM:
+    randint t -> q_sample -> UNet forward -> ELBO -> backward -> (gradient all-reduce when N > 1) -> Adam step
+on the workload of BASELINE.json configs[1] (32x32x1 images, batch 256 per GPU, stages [32,64,128,256], T=120,
+bf16 MFMA compute with fp32 accumulation / fp32 master weights, dropout 0.1 active).  value = trained images/s of
+the whole job.  Also reported on the same line: sampled images/s of the full T-step ancestral chain, a roofline
+entry for the dominant kernel and a bounded CPU baseline (the oracle timed on the host cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import dm_amd_bootstrap  # noqa: E402,F401
+from dm_amd.losses.ELBO import ELBOLoss  # noqa: E402
+from dm_amd.neural_nets.denoise_models import ddpm as dm_ddpm, unets as dm_unets  # noqa: E402
+from dm_amd.runtime import graphs  # noqa: E402
+
+YAML = dict(stages_channels=[32, 64, 128, 256], expand_factor=2, drop_p=0.1, T=120, beta=0.25, t_embed_dim=32, activation="gelu",
+            base_groups_norm=4, initializer="he_normal", dtype=None)
+
+
+def build_model(dev, channels):
+    torch.manual_seed(42 + int(os.environ.get("RANK", 0)))
+    m = dm_ddpm.DDPM(dm_unets.BaseUNet, **YAML, is_conditional=False, img_channels=channels, reconstruction_method="mse",
+                     latent_dim=512, device=dev)
+    return m.to(dev)
+
+
+def cpu_baseline(channels, size, batch, steps):
+    """The oracle (CPU restatement of the reference) timed on the host cores: same train step, bounded sample."""
+    from oracle import ref_cpu as O
+    torch.manual_seed(42)
+    cfg = O.UNetCfg(img_channels=channels, drop_p=0.1)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.hash_params(cfg).items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    s = O.make_schedule(120, 0.25)
+    x0 = torch.rand(batch, channels, size, size) * 2 - 1
+    gen = torch.Generator().manual_seed(1)
+
+    def step():
+        t = torch.randint(1, 121, (batch,))
+        masks = O.draw_drop_masks(p, cfg, x0, t, gen)
+        x_t = O.q_sample(s, x0, t, torch.randn_like(x0))
+        pred = O.unet_forward(p, cfg, x_t, t, drop=O.DropMasks(masks))
+        loss = O.elbo_loss(s, t, pred, x0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps of batch {batch} at {size}x{size}x{channels} (oracle/ref_cpu.py, fp32, dropout on, Adam)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=32)
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--sample-batch", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-sample", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)
+
+    m = build_model(dev, a.channels)
+    m.train()
+    crit = ELBOLoss("mse")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, capturable=True)
+    x0 = (torch.rand(a.batch, a.channels, a.size, a.size, device=dev) * 2 - 1)
+
+    after = None
+    if dist:
+        from dm_amd.runtime.dp import GradReducer
+        reducer = GradReducer(list(m.parameters()), world)
+        reducer.broadcast_parameters()
+        after = reducer.allreduce
+    step = graphs.GraphedTrainStep(m, crit, opt, x0, after_backward=after, use_graph=not a.no_graph)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step.replay()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step.replay()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = tt.item()
+    loss = step.replay().item()
+    train_ips = a.batch * world * a.steps / dt
+
+    out = {
+        "metric": "train imgs/sec (q_sample + UNet fwd + ELBO + bwd + Adam step), sampled imgs/sec reported alongside",
+        "value": train_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"DDPM train step, {a.size}x{a.size}x{a.channels} (FashionMNIST-shaped), batch {a.batch}/GPU, "
+                               f"stages [32,64,128,256], T=120, drop_p=0.1, Adam, gradient_accumulation_steps=1",
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
+        "final_loss": loss,
+    }
+
+    if not a.no_sample:
+        m.eval()
+        nb = a.sample_batch
+        sampler = graphs.GraphedSampler(m, nb, (a.size, a.size), use_graph=not a.no_graph)
+        sampler.sample()
+        barrier()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            sampler.sample()
+        barrier()
+        ds = (time.perf_counter() - t0) / reps
+        if dist:
+            tt = torch.tensor([ds], device=dev, dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            ds = tt.item()
+        out["sampling"] = {"value": nb * world / ds, "unit": "images/s", "chain_steps": 120, "batch_per_gpu": nb,
+                           "ms_per_chain": 1e3 * ds, "ms_per_step": 1e3 * ds / 120}
+        m.train()
+
+    if rank == 0 and not a.no_roofline:
+        from dm_amd.runtime import roofline
+        out["roofline"] = roofline.measure(m, crit, a.batch, a.channels, a.size)
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a.channels, a.size, 64, 3)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

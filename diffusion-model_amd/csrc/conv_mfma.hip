@@ -28,13 +28,20 @@ struct ConvArgs {
     float* sum_out;                  // optional fp32 [N][Cout] per-image sums of the activated output (atomics)
 };
 
-template <int WAVES, int NT>
-__global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a) {
-    constexpr int T = 64 * WAVES, BM = 32 * WAVES, BN = 32 * NT;
+// Loads are issued in batches of STAGE_U per thread before any of them is consumed, so that each thread keeps
+// several 16-byte requests in flight (the tensors are mostly L2 / Infinity-Cache resident: latency, not bandwidth,
+// is what a one-load-at-a-time loop would pay).
+#define STAGE_U 4
+
+template <int WM, int WN, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int T = 256, BM = 32 * WM, BNW = 32 * NT, BN = BNW * WN;
     constexpr int OS = BN * 2 + 16;   // epilogue LDS row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_m = (tid >> 6) % WM, wave_n = (tid >> 6) / WM;
+    const int wave = wave_m;          // row group of this wave inside the tile
     const int cls = blockIdx.z;
     const int tap0 = g.cls_tap_begin[cls], ntaps = g.cls_tap_begin[cls + 1] - tap0;
     const int co0 = blockIdx.y * BN;
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
     const int il = pidx / thw, rem = pidx - il * thw;
     const int ty = rem / g.TW, tx = rem - ty * g.TW;
     const int a_base = (il * PHW + ty * g.SI * g.PW + tx * g.SI) * CONV_RS + (lane >> 5) * 16;
-    const int b_base = (lane & 31) * CONV_RS + (lane >> 5) * 16;
+    const int b_base = (wave_n * BNW + (lane & 31)) * CONV_RS + (lane >> 5) * 16;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -82,38 +89,67 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
         const bool src1 = c0 >= a.C0;
         const bf16* src = src1 ? a.in1 : a.in0;
         const int cs = src1 ? a.C1 : a.C0, cc = src1 ? c0 - a.C0 : c0;
-        for (int it = tid; it < npix * 4; it += T) {
-            const int p = it >> 2, part = it & 3;
-            if (part >= parts) continue;
-            const int pl = s_pl[p];
-            bf16x8 v;
+        const bool xform = !src1 && (a.in_add || a.in_mask);
+        for (int base = tid; base < npix * 4; base += T * STAGE_U) {
+            bf16x8 v[STAGE_U];
+            long long e[STAGE_U];
+            int pl[STAGE_U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
-            if (pl >= 0) {
-                const long long e = (long long)pl * cs + cc + part * 8;
-                v = *(const bf16x8*)(src + e);
-                if (!src1) {
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int it = base + u * T;
+                const int p = it >> 2, part = it & 3;
+                pl[u] = (it < npix * 4 && part < parts) ? s_pl[p] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int part = (base + u * T) & 3;
+                e[u] = (long long)pl[u] * cs + cc + part * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+                if (pl[u] >= 0) v[u] = *(const bf16x8*)(src + e[u]);
+            }
+            if (xform) {
+#pragma unroll
+                for (int u = 0; u < STAGE_U; ++u) {
+                    if (pl[u] < 0) continue;
+                    const int part = (base + u * T) & 3;
                     if (a.in_add) {
-                        const float* ad = a.in_add + (pl / ihw) * a.C0 + cc + part * 8;
+                        const float* ad = a.in_add + (pl[u] / ihw) * a.C0 + cc + part * 8;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + ad[j]);
+                        for (int j = 0; j < 8; ++j) v[u][j] = (bf16)((float)v[u][j] + ad[j]);
                     }
                     if (a.in_mask) {
-                        const unsigned m = a.in_mask[e >> 3];
+                        const unsigned m = a.in_mask[e[u] >> 3];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.in_mask_scale) : (bf16)0.f;
+                        for (int j = 0; j < 8; ++j) v[u][j] = (m >> j) & 1 ? (bf16)((float)v[u][j] * a.in_mask_scale) : (bf16)0.f;
                     }
                 }
             }
-            *(bf16x8*)(s_patch + p * CONV_RS + part * 16) = v;
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int it = base + u * T;
+                const int p = it >> 2, part = it & 3;
+                if (it < npix * 4 && part < parts) *(bf16x8*)(s_patch + p * CONV_RS + part * 16) = v[u];
+            }
         }
         // -- stage weights: rows = (tap, out channel), 32 input channels each
-        for (int it = tid; it < ntaps * BN * 4; it += T) {
-            const int row = it >> 2, part = it & 3;
-            if (part >= parts) continue;
-            const int j = row / BN, co = row - j * BN;
-            const bf16* wp = a.w + ((long long)g.tap_slice[tap0 + j] * a.w_rows + co0 + co) * Cin + c0 + part * 8;
-            *(bf16x8*)(s_w + row * CONV_RS + part * 16) = *(const bf16x8*)wp;
+        for (int base = tid; base < ntaps * BN * 4; base += T * STAGE_U) {
+            bf16x8 v[STAGE_U];
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int it = base + u * T;
+                const int row = it >> 2, part = it & 3;
+                if (it < ntaps * BN * 4 && part < parts) {
+                    const int j = row / BN, co = row - j * BN;
+                    v[u] = *(const bf16x8*)(a.w + ((long long)g.tap_slice[tap0 + j] * a.w_rows + co0 + co) * Cin + c0 + part * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int it = base + u * T;
+                const int row = it >> 2, part = it & 3;
+                if (it < ntaps * BN * 4 && part < parts) *(bf16x8*)(s_w + row * CONV_RS + part * 16) = v[u];
+            }
         }
         __syncthreads();
         // -- MFMA over taps x k-steps
@@ -137,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
         // per-image spatial sums from the fp32 accumulators (before any rounding, mask or residual)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int co = co0 + nt * 32 + (lane & 31);
+            const int co = co0 + wave_n * BNW + nt * 32 + (lane & 31);
             const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
             float run = 0.f;
             int run_n = -1;
@@ -163,7 +199,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
         float* out = (float*)a.out;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int co = co0 + nt * 32 + (lane & 31);
+            const int co = co0 + wave_n * BNW + nt * 32 + (lane & 31);
             if (co >= a.Cout) continue;
             const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
@@ -183,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
     char* s_out = smem;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int col = nt * 32 + (lane & 31);
+        const int col = wave_n * BNW + nt * 32 + (lane & 31);
         const float b = (a.bias && co0 + col < a.Cout) ? a.bias[co0 + col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -223,16 +259,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv_mfma_kernel(const ConvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <int WAVES, int NT>
+template <int WM, int WN, int NT>
 static int launch_conv(const ConvArgs& a, size_t lds, hipStream_t stream) {
     const ConvGeom& g = a.g;
-    auto k = conv_mfma_kernel<WAVES, NT>;
+    auto k = conv_mfma_kernel<WM, WN, NT>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ddpm_check_launch("conv: raise dynamic LDS limit");
     }
-    dim3 grid(g.tiles_n * g.tiles_h * g.tiles_w, a.CoutW / (32 * NT), g.ncls);
-    hipLaunchKernelGGL(k, grid, dim3(64 * WAVES), lds, stream, a);
+    dim3 grid(g.tiles_n * g.tiles_h * g.tiles_w, a.CoutW / (32 * NT * WN), g.ncls);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, a);
     return ddpm_check_launch("conv_mfma");
 }
 
@@ -252,21 +288,27 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
 
     ConvArgs a;
-    const long long positions_guess = (long long)d->N * d->IH * d->IW;
-    // tile height along M: 128 positions normally, 64 when the whole layer would otherwise fill < 1/2 of the CUs
-    int nt = d->CoutW / 32;
+    // Tile choice.  Workgroup = 4 waves as WM x WN; tile = (32*WM) positions x (32*NT*WN) output channels.
+    // Start from the largest tile (most operand reuse) and shrink it until the launch has >= 384 workgroups
+    // (1.5 per CU) or cannot shrink further: these layers are latency/bandwidth bound, so parallelism wins.
     const int kind_taps = (d->kind == CONV_3X3_S1 || d->kind == CONV_3X3_S2) ? 9 : 4;
-    const int nt_cap = kind_taps >= 9 ? 2 : 4;
-    if (nt > nt_cap) nt = nt_cap;
-    if (nt == 3) nt = 2;
-    while ((d->CoutW / 32) % nt) --nt;
-    int waves = 4;
-    if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 128) != 0) { ddpm_set_error("conv: geometry"); return DDPM_EINVAL; }
-    {
-        const long long blocks = (long long)a.g.tiles_n * a.g.tiles_h * a.g.tiles_w * (d->CoutW / (32 * nt)) * a.g.ncls;
-        if (blocks < 192 && positions_guess >= 64) waves = 2;
+    const int co32 = d->CoutW / 32;
+    struct Cfg { int wm, wn, nt; };
+    const Cfg cands[] = {{4, 1, 4}, {4, 1, 2}, {2, 2, 2}, {4, 1, 1}, {2, 2, 1}};
+    int pick = -1;
+    for (int i = 0; i < 5; ++i) {
+        const Cfg c = cands[i];
+        const int bn32 = c.nt * c.wn;
+        if (co32 % bn32) continue;
+        if (kind_taps >= 9 && bn32 > 2) continue;                 // 9 taps x 128 rows of weights would not fit LDS comfortably
+        if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 32 * c.wm) != 0) { ddpm_set_error("conv: geometry"); return DDPM_EINVAL; }
+        const long long blocks = (long long)a.g.tiles_n * a.g.tiles_h * a.g.tiles_w * (co32 / bn32) * a.g.ncls;
+        pick = i;
+        if (blocks >= 384) break;
     }
-    if (waves == 2) conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 64);
+    DDPM_REQUIRE(pick >= 0, "conv: no tile configuration for CoutW=%d", d->CoutW);
+    const Cfg cfg = cands[pick];
+    conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 32 * cfg.wm);
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1;
     a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = d->out; a.res = (const bf16*)d->res;
@@ -274,15 +316,15 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.out_mode = d->out_mode; a.sum_out = d->sum_out;
 
     const int npix = a.g.NB * a.g.PH * a.g.PW;
-    const int bm = 32 * waves, bn = 32 * nt;
+    const int bm = 32 * cfg.wm, bn = 32 * cfg.nt * cfg.wn;
     size_t lds = ((size_t)npix * 4 + 15) / 16 * 16 + (size_t)npix * CONV_RS + (size_t)a.g.max_taps * bn * CONV_RS;
     const size_t lds_out = (size_t)bm * (bn * 2 + 16);
     if (lds < lds_out) lds = lds_out;
     DDPM_REQUIRE(lds <= 160 * 1024, "conv: tile needs %zu B of LDS", lds);
 
-#define CONV_CASE(W, NTv) if (waves == W && nt == NTv) return launch_conv<W, NTv>(a, lds, stream);
-    CONV_CASE(4, 1) CONV_CASE(4, 2) CONV_CASE(4, 4) CONV_CASE(2, 1) CONV_CASE(2, 2) CONV_CASE(2, 4)
+#define CONV_CASE(WMv, WNv, NTv) if (cfg.wm == WMv && cfg.wn == WNv && cfg.nt == NTv) return launch_conv<WMv, WNv, NTv>(a, lds, stream);
+    CONV_CASE(4, 1, 4) CONV_CASE(4, 1, 2) CONV_CASE(2, 2, 2) CONV_CASE(4, 1, 1) CONV_CASE(2, 2, 1)
 #undef CONV_CASE
-    ddpm_set_error("conv: no kernel for waves=%d nt=%d", waves, nt);
+    ddpm_set_error("conv: no kernel for tile %dx%dx%d", cfg.wm, cfg.wn, cfg.nt);
     return DDPM_EINVAL;
 }

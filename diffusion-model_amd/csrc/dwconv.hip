@@ -7,38 +7,60 @@
 #include "common.h"
 #include "ddpm_hip.h"
 
+// One thread produces PX horizontally adjacent pixels x 8 channels: per kernel row it loads the PX+2 input
+// vectors once and reuses them across the PX outputs, and loads the row's 3x8 weights once.
+template <int PX>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, bf16* __restrict__ y, int N, int H, int W,
                                                          int C) {
-    const int cvs = C / 8;
-    const long long total = (long long)N * H * W * cvs;
+    const int cvs = C / 8, wq = W / PX;
+    const long long total = (long long)N * H * wq * cvs;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int cv = (int)(i % cvs);
-        const long long pix = i / cvs;
-        const int wx = (int)(pix % W);
-        const int hy = (int)((pix / W) % H);
+        long long r = i / cvs;
+        const int wx = (int)(r % wq) * PX; r /= wq;
+        const int hy = (int)(r % H);
+        const long long n = r / H;
         const int c = cv * 8;
-        float acc[8];
+        float acc[PX][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c + j] : 0.f;
+        for (int q = 0; q < PX; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[q][j] = bias ? bias[c + j] : 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int iy = hy + kh - 1;
             if (iy < 0 || iy >= H) continue;
+            const bf16* row = x + ((n * H + iy) * W) * C + c;
+            bf16x8 v[PX + 2];
+#pragma unroll
+            for (int q = 0; q < PX + 2; ++q) {
+                const int ix = wx + q - 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[q][j] = (bf16)0.f;
+                if (ix >= 0 && ix < W) v[q] = *(const bf16x8*)(row + (long long)ix * C);
+            }
+            float wk[3][8];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int ix = wx + kw - 1;
-                if (ix < 0 || ix >= W) continue;
-                const bf16x8 v = *(const bf16x8*)(x + (pix + (kh - 1) * W + (kw - 1)) * C + c);
-                const float* wp = w + (kh * 3 + kw) * C + c;
+                const f32x4 w0 = *(const f32x4*)(w + (kh * 3 + kw) * C + c), w1 = *(const f32x4*)(w + (kh * 3 + kw) * C + c + 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * wp[j];
+                for (int j = 0; j < 4; ++j) { wk[kw][j] = w0[j]; wk[kw][4 + j] = w1[j]; }
             }
-        }
-        bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
-        *(bf16x8*)(y + pix * C + c) = o;
+            for (int q = 0; q < PX; ++q)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[q][j] += (float)v[q + kw][j] * wk[kw][j];
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[q][j];
+            *(bf16x8*)(y + ((n * H + hy) * W + wx + q) * C + c) = o;
+        }
     }
 }
 
@@ -47,18 +69,24 @@ extern "C" int ddpm_dwconv3x3_forward(const void* x, const float* w, const float
     hipStream_t stream = (hipStream_t)stream_;
     DDPM_REQUIRE(x && w && y, "dwconv: null pointer");
     DDPM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "dwconv: C (%d) must be a positive multiple of 8", C);
-    const long long total = (long long)N * H * W * (C / 8);
+    const int px = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
+    const long long total = (long long)N * H * (W / px) * (C / 8);
     long long grid = (total + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
+    if (px == 4) hipLaunchKernelGGL(dwconv3x3_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
+    else if (px == 2) hipLaunchKernelGGL(dwconv3x3_kernel<2>, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
+    else hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
     return ddpm_check_launch("dwconv3x3");
 }
 
-// dw[tap][c] += sum_{n,h,w} dy[n,h,w,c] * x[n,h+kh-1,w+kw-1,c];  db[c] += sum dy.
+// part[b][t][c]: t < 9: sum over the block's pixel strip of dy[n,h,w,c] * x[n,h+kh-1,w+kw-1,c]; t = 9: sum of dy.
 // Thread layout: 256 threads = (256/cvs) pixel lanes x cvs channel vectors (cvs = C/8, a power of two <= 64).
+// Lanes of a wave that share a channel vector are combined with shuffles, the four waves through LDS; the
+// workgroup then stores its [10][C] partial with plain stores (a second pass sums over workgroups).
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
-                                                               float* __restrict__ dw, float* __restrict__ db, int N, int H, int W,
-                                                               int C, int pix_per_block) {
+                                                               float* __restrict__ part, int N, int H, int W, int C,
+                                                               int pix_per_block) {
+    extern __shared__ float s_part[];      // [4 waves][80][lo]
     const int cvs = C / 8;
     const int cv = threadIdx.x % cvs, prow = threadIdx.x / cvs, pstep = 256 / cvs;
     const long long npix = (long long)N * H * W;
@@ -77,57 +105,76 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16* __rest
         const int wx = (int)(pix % W);
         const int hy = (int)((pix / W) % H);
         const bf16x8 g = *(const bf16x8*)(dy + pix * C + c);
+        bf16x8 v[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iy = hy + kh - 1, ix = wx + kw - 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[kh * 3 + kw][j] = (bf16)0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[kh * 3 + kw] = *(const bf16x8*)(x + (pix + (kh - 1) * W + (kw - 1)) * C + c);
+            }
         float gf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { gf[j] = (float)g[j]; sb[j] += gf[j]; }
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int iy = hy + kh - 1;
-            if (iy < 0 || iy >= H) continue;
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ix = wx + kw - 1;
-                if (ix < 0 || ix >= W) continue;
-                const bf16x8 v = *(const bf16x8*)(x + (pix + (kh - 1) * W + (kw - 1)) * C + c);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] += gf[j] * (float)v[j];
-            }
-        }
+            for (int j = 0; j < 8; ++j) acc[t][j] += gf[j] * (float)v[t][j];
     }
-    // combine the lanes of a wave that hold the same channel vector, then one atomic per wave
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = cvs < 64 ? cvs : 64;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = acc[t][j];
+            float v = t < 9 ? acc[t < 9 ? t : 0][j] : sb[j];
             for (int o = 32; o >= lo; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane < lo) atomicAdd(dw + t * C + c + j, v);
+            if (lane < lo) s_part[(wave * 80 + t * 8 + j) * lo + lane] = v;
         }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = sb[j];
-        for (int o = 32; o >= lo; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane < lo && db) atomicAdd(db + c + j, v);
+    __syncthreads();
+    // waves hold disjoint channel vectors when cvs > 64 is impossible (cvs <= 64): every wave covers vectors
+    // lane % cvs, so the same `lo` vectors appear in all four waves -> sum the four copies
+    float* out = part + (long long)blockIdx.x * 10 * C;
+    for (int i = threadIdx.x; i < 80 * lo; i += 256) {
+        const int k = i / lo, l = i - k * lo;           // k = t*8 + j, l = channel vector
+        const float v = s_part[(0 * 80 + k) * lo + l] + s_part[(1 * 80 + k) * lo + l] + s_part[(2 * 80 + k) * lo + l] + s_part[(3 * 80 + k) * lo + l];
+        out[(k >> 3) * C + l * 8 + (k & 7)] = v;
     }
 }
 
-extern "C" int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* db, int N, int H, int W, int C,
-                                    ddpm_stream_t stream_) {
+static void dw_wgrad_split(int N, int H, int W, int C, int* blocks, int* ppb) {
+    const long long npix = (long long)N * H * W;
+    const int cvs = C / 8;
+    long long b = (npix * cvs + 256 * 8 - 1) / (256 * 8);     // ~8 pixels per thread: partials stay ~10 % of the input bytes
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    *ppb = (int)((npix + b - 1) / b);
+    *blocks = (int)((npix + *ppb - 1) / *ppb);
+}
+
+extern "C" int ddpm_dwconv3x3_wgrad_blocks(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return 0;
+    int blocks, ppb;
+    dw_wgrad_split(N, H, W, C, &blocks, &ppb);
+    return blocks;
+}
+
+extern "C" int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* part, int N, int H, int W, int C, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DDPM_REQUIRE(x && dy && dw, "dwconv_wgrad: null pointer");
+    DDPM_REQUIRE(x && dy && part, "dwconv_wgrad: null pointer");
     const int cvs = C / 8;
     DDPM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 8 == 0 && cvs >= 1 && cvs <= 64 && (cvs & (cvs - 1)) == 0,
                  "dwconv_wgrad: C (%d) must be 8 * a power of two <= 512", C);
-    const long long npix = (long long)N * H * W;
-    // enough blocks to fill the chip, each with a strip long enough to amortise its 80 atomics per wave lane-group
-    long long blocks = (npix * cvs + 256 * 32 - 1) / (256 * 32);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    const int ppb = (int)((npix + blocks - 1) / blocks);
-    blocks = (npix + ppb - 1) / ppb;
-    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, dw, db, N, H,
+    int blocks, ppb;
+    dw_wgrad_split(N, H, W, C, &blocks, &ppb);
+    const size_t lds = (size_t)4 * 80 * cvs * sizeof(float);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)dwconv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ddpm_check_launch("dwconv_wgrad: raise dynamic LDS limit");
+    }
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, (const bf16*)x, (const bf16*)dy, part, N, H,
                        W, C, ppb);
     return ddpm_check_launch("dwconv3x3_wgrad");
 }

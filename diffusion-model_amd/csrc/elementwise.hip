@@ -427,3 +427,34 @@ extern "C" int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int ns
                        (const long long*)offsets, nsites, (long long)total_bytes, thresh, (const unsigned long long*)seed);
     return ddpm_check_launch("dropout_masks");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Second stage of the deterministic two-stage reductions (GroupNorm / bias / depthwise parameter gradients):
+// for each table entry, dst[dst_off + j] += sum_r src[src_off + r*row_stride + j].  One launch for all layers.
+// Workgroup = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           const ddpm_reduce_entry* __restrict__ entries) {
+    __shared__ float s[4][64];
+    const ddpm_reduce_entry e = entries[blockIdx.y];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (blockIdx.x * 64 >= e.width) return;
+    const int rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (col < e.width) {
+        const float* p = src + e.src_off + col;
+#pragma unroll 4
+        for (int r = rl; r < e.rows; r += 4) acc += p[(long long)r * e.row_stride];
+    }
+    s[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < e.width) dst[e.dst_off + col] += s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+extern "C" int ddpm_reduce_rows(const float* src, float* dst, const ddpm_reduce_entry* entries, int n_entries, int max_width,
+                                ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(src && dst && entries && n_entries > 0 && max_width > 0, "reduce_rows: bad arguments");
+    DDPM_REQUIRE(n_entries <= 65535, "reduce_rows: too many entries");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((max_width + 63) / 64, n_entries), dim3(256), 0, stream, src, dst, entries);
+    return ddpm_check_launch("reduce_rows");
+}

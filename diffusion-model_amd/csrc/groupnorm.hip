@@ -23,8 +23,8 @@ struct GnArgs {
     float* stats;              // [N][G][2] mean, rstd (written by forward, read by backward)
     // backward only
     const bf16* dy;
-    float* dgamma; float* dbeta;   // [C] fp32, accumulated with atomics (caller zeroes)
-    float* dbias;                  // [C] fp32: sum of dx over n,h,w = gradient of the producing conv's bias (nullable)
+    float* part;                   // [N][3][C] fp32 per-image partial sums: dgamma, dbeta, sum of dx (= the producing conv's
+                                   // bias gradient); every element is written exactly once, a later pass sums over N
     int N, HW, C, G, SC;           // SC = slab width (channels)
     int act;
     float eps;
@@ -58,9 +58,13 @@ __device__ __forceinline__ void block_reduce_cols(float (&v)[8], int vps, float*
     }
 }
 
-template <int THREADS>
+// NV = vectors a thread keeps in registers when the whole slab fits (CACHED): the slab is then read from memory
+// exactly once, with all of a thread's loads in flight together; otherwise two passes with 4-way unrolled loops.
+#define GN_NV 8
+
+template <int THREADS, bool CACHED>
 __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
-    __shared__ float s_red[256];
+    __shared__ float s_red[(THREADS / 64) * 64 < 128 ? 128 : (THREADS / 64) * 64];
     __shared__ float s_mean[32], s_rstd[32];
     const int tid = threadIdx.x;
     const int slabs = a.C / a.SC;
@@ -70,16 +74,37 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
     const int cpg = a.G > 0 ? a.C / a.G : 1;
 
+    bf16x8 xv[GN_NV];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int k = 0; k < GN_NV; ++k) {
+            const int p = prow + k * pstep;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[k][j] = (bf16)0.f;
+            if (p < a.HW) xv[k] = *(const bf16x8*)(a.x + base + (long long)p * a.C);
+        }
+    }
     if (a.G > 0) {
         float s[8], ss[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
-        for (int p = prow; p < a.HW; p += pstep) {
-            const bf16x8 v = *(const bf16x8*)(a.x + base + (long long)p * a.C);
+        if constexpr (CACHED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float f = (float)v[j];
-                s[j] += f; ss[j] += f * f;
+            for (int k = 0; k < GN_NV; ++k)       // out-of-range slots hold zeros and add nothing
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = (float)xv[k][j];
+                    s[j] += f; ss[j] += f * f;
+                }
+        } else {
+#pragma unroll 2
+            for (int p = prow; p < a.HW; p += pstep) {
+                const bf16x8 v = *(const bf16x8*)(a.x + base + (long long)p * a.C);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = (float)v[j];
+                    s[j] += f; ss[j] += f * f;
+                }
             }
         }
         block_reduce_cols<THREADS>(s, vps, s_red, tid);
@@ -119,9 +144,7 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
             sc[j] = 1.f; sh[j] = 0.f;
         }
     }
-    for (int p = prow; p < a.HW; p += pstep) {
-        const long long e = base + (long long)p * a.C;
-        const bf16x8 v = *(const bf16x8*)(a.x + e);
+    auto finish = [&](const bf16x8& v, long long e) {
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act);
@@ -139,15 +162,28 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = (bf16)o[j];
         *(bf16x8*)(a.y + e) = w;
+    };
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int k = 0; k < GN_NV; ++k) {
+            const int p = prow + k * pstep;
+            if (p < a.HW) finish(xv[k], base + (long long)p * a.C);
+        }
+    } else {
+#pragma unroll 2
+        for (int p = prow; p < a.HW; p += pstep) {
+            const long long e = base + (long long)p * a.C;
+            finish(*(const bf16x8*)(a.x + e), e);
+        }
     }
 }
 
 // Backward.  With g = dy * mask * act'(z), xhat = (x - mean) rstd, m = cpg*HW:
 //   dgamma_c = sum g xhat,  dbeta_c = sum g,
 //   dx = rstd * ( gamma_c g - (S1 + xhat S2)/m ),  S1 = sum_group gamma g,  S2 = sum_group gamma g xhat.
-template <int THREADS>
+template <int THREADS, bool CACHED>
 __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
-    __shared__ float s_red[256];
+    __shared__ float s_red[(THREADS / 64) * 64 < 128 ? 128 : (THREADS / 64) * 64];
     __shared__ float s_s1[32], s_s2[32];
     const int tid = threadIdx.x;
     const int slabs = a.C / a.SC;
@@ -170,6 +206,30 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
             ga[j] = 1.f; be[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f;
         }
     }
+    // g and xhat of one vector
+    auto gx = [&](const bf16x8& xv, const bf16x8& dv, long long e, float (&g)[8], float (&xh)[8]) {
+        const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+        const float ms = a.mask ? a.mask_scale : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xh[j] = ((float)xv[j] - mean[j]) * rstd[j];
+            const float gg = (float)dv[j] * act_bwd(xh[j] * ga[j] + be[j], a.act) * ms;
+            g[j] = (m >> j) & 1 ? gg : 0.f;
+        }
+    };
+    bf16x8 xc[GN_NV], dc[GN_NV];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int k = 0; k < GN_NV; ++k) {
+            const int p = prow + k * pstep;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xc[k][j] = (bf16)0.f; dc[k][j] = (bf16)0.f; }
+            if (p < a.HW) {
+                xc[k] = *(const bf16x8*)(a.x + base + (long long)p * a.C);
+                dc[k] = *(const bf16x8*)(a.dy + base + (long long)p * a.C);
+            }
+        }
+    }
     float S1[8], S2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) S1[j] = S2[j] = 0.f;
@@ -177,17 +237,25 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
         float a1[8], a2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
-        for (int p = prow; p < a.HW; p += pstep) {
-            const long long e = base + (long long)p * a.C;
-            const bf16x8 xv = *(const bf16x8*)(a.x + e);
-            const bf16x8 dv = *(const bf16x8*)(a.dy + e);
-            const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+        if constexpr (CACHED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = ((float)xv[j] - mean[j]) * rstd[j];
-                float g = (float)dv[j] * act_bwd(xh * ga[j] + be[j], a.act);
-                g = (m >> j) & 1 ? (a.mask ? g * a.mask_scale : g) : 0.f;
-                a1[j] += g; a2[j] += g * xh;
+            for (int k = 0; k < GN_NV; ++k) {
+                const int p = prow + k * pstep;
+                if (p < a.HW) {
+                    float g[8], xh[8];
+                    gx(xc[k], dc[k], base + (long long)p * a.C, g, xh);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int p = prow; p < a.HW; p += pstep) {
+                const long long e = base + (long long)p * a.C;
+                float g[8], xh[8];
+                gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
             }
         }
         block_reduce_cols<THREADS>(a1, vps, s_red, tid);
@@ -197,8 +265,8 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int cl = tid * 8 + j;
-                atomicAdd(a.dbeta + c0 + cl, a1[j]);
-                atomicAdd(a.dgamma + c0 + cl, a2[j]);
+                a.part[((long long)n * 3 + 0) * a.C + c0 + cl] = a2[j];
+                a.part[((long long)n * 3 + 1) * a.C + c0 + cl] = a1[j];
                 s_red[cl] = a1[j] * ga[j];
                 s_red[64 + cl] = a2[j] * ga[j];
             }
@@ -221,29 +289,35 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
     float db[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) db[j] = 0.f;
-    for (int p = prow; p < a.HW; p += pstep) {
-        const long long e = base + (long long)p * a.C;
-        const bf16x8 xv = *(const bf16x8*)(a.x + e);
-        const bf16x8 dv = *(const bf16x8*)(a.dy + e);
-        const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+    auto emit = [&](const bf16x8& xv, const bf16x8& dv, long long e) {
+        float g[8], xh[8];
+        gx(xv, dv, e, g, xh);
         bf16x8 w;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float xh = ((float)xv[j] - mean[j]) * rstd[j];
-            float g = (float)dv[j] * act_bwd(xh * ga[j] + be[j], a.act);
-            g = (m >> j) & 1 ? (a.mask ? g * a.mask_scale : g) : 0.f;
-            const float dx = rstd[j] * (ga[j] * g - (S1[j] + xh * S2[j]));
+            const float dx = rstd[j] * (ga[j] * g[j] - (S1[j] + xh[j] * S2[j]));
             db[j] += dx;
             w[j] = (bf16)dx;
         }
         *(bf16x8*)(a.y + e) = w;
-    }
-    if (a.dbias) {
-        block_reduce_cols<THREADS>(db, vps, s_red, tid);
-        if (tid < vps) {
+    };
+    if constexpr (CACHED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(a.dbias + c0 + tid * 8 + j, db[j]);
+        for (int k = 0; k < GN_NV; ++k) {
+            const int p = prow + k * pstep;
+            if (p < a.HW) emit(xc[k], dc[k], base + (long long)p * a.C);
         }
+    } else {
+#pragma unroll 2
+        for (int p = prow; p < a.HW; p += pstep) {
+            const long long e = base + (long long)p * a.C;
+            emit(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e);
+        }
+    }
+    block_reduce_cols<THREADS>(db, vps, s_red, tid);
+    if (tid < vps) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a.part[((long long)n * 3 + 2) * a.C + c0 + tid * 8 + j] = db[j];
     }
 }
 
@@ -252,29 +326,40 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     DDPM_REQUIRE(d->N > 0 && d->HW > 0 && d->C > 0 && d->C % 8 == 0, "%s: C (%d) must be a positive multiple of 8", what, d->C);
     DDPM_REQUIRE(d->G >= 0 && (d->G == 0 || (d->C % d->G == 0 && (d->gamma && d->beta && d->stats))),
                  "%s: groups %d must divide C %d (and gamma/beta/stats must be given)", what, d->G, d->C);
-    int sc = d->C < 64 ? d->C : 64;
-    while (d->C % sc) sc -= 8;
-    if (d->G > 0) {
-        const int cpg = d->C / d->G;
-        DDPM_REQUIRE(cpg <= 64 && (cpg >= 8 ? cpg % 8 == 0 : 8 % cpg == 0), "%s: unsupported channels per group %d", what, cpg);
-        DDPM_REQUIRE(sc % cpg == 0 && sc / cpg <= 32, "%s: slab %d not a multiple of the group width %d", what, sc, cpg);
+    // slab width: the widest of 64/32/16/8 channels that holds whole groups and whose slab (HW x SC) fits the
+    // register cache of a 512-thread workgroup; if none fits, the narrowest valid width on the two-pass path
+    const int cpg = d->G > 0 ? d->C / d->G : 1;
+    if (d->G > 0) DDPM_REQUIRE(cpg <= 64 && (cpg >= 8 ? cpg % 8 == 0 : 8 % cpg == 0), "%s: unsupported channels per group %d", what, cpg);
+    int sc = 0, sc_min = 0;
+    for (int c = 64; c >= 8; c >>= 1) {
+        if (d->C % c || c % cpg || c / cpg > 32) continue;
+        sc_min = c;
+        if (!sc && (long long)d->HW * (c / 8) <= 512 * GN_NV) sc = c;
     }
-    DDPM_REQUIRE(sc == 8 || sc == 16 || sc == 32 || sc == 64, "%s: slab width %d must be 8/16/32/64", what, sc);
+    if (!sc) sc = sc_min;
+    DDPM_REQUIRE(sc > 0, "%s: no slab width for C=%d, groups=%d", what, d->C, d->G);
     a.x = (const bf16*)d->x; a.gamma = d->gamma; a.beta = d->beta; a.res = (const bf16*)d->res; a.mask = d->mask;
-    a.mask_scale = d->mask_scale; a.y = (bf16*)d->y; a.stats = d->stats; a.dy = (const bf16*)d->dy; a.dgamma = d->dgamma;
-    a.dbeta = d->dbeta; a.dbias = d->dbias; a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.SC = sc; a.act = d->act;
+    a.mask_scale = d->mask_scale; a.y = (bf16*)d->y; a.stats = d->stats; a.dy = (const bf16*)d->dy; a.part = d->part;
+    a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.SC = sc; a.act = d->act;
     a.eps = d->eps;
     return DDPM_OK;
 }
+
+// Pick the workgroup size: the smallest of 64 / 256 / 512 threads whose registers can hold the whole slab
+// (GN_NV vectors per thread); slabs too large even for 512 threads take the two-pass path.
+#define GN_DISPATCH(KERNEL)                                                                                   \
+    const int units = a.N * (a.C / a.SC);                                                                     \
+    const long long vecs = (long long)a.HW * (a.SC / 8);                                                      \
+    if (vecs <= 64 * GN_NV) hipLaunchKernelGGL((KERNEL<64, true>), dim3(units), dim3(64), 0, stream, a);       \
+    else if (vecs <= 256 * GN_NV) hipLaunchKernelGGL((KERNEL<256, true>), dim3(units), dim3(256), 0, stream, a); \
+    else if (vecs <= 512 * GN_NV) hipLaunchKernelGGL((KERNEL<512, true>), dim3(units), dim3(512), 0, stream, a); \
+    else hipLaunchKernelGGL((KERNEL<512, false>), dim3(units), dim3(512), 0, stream, a);
 
 extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GnArgs a;
     if (int rc = gn_prepare(a, d, "gn_forward")) return rc;
-    const int units = a.N * (a.C / a.SC);
-    const long long vecs = (long long)a.HW * (a.SC / 8);
-    if (vecs <= 128) hipLaunchKernelGGL(gn_fwd_kernel<64>, dim3(units), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(gn_fwd_kernel<256>, dim3(units), dim3(256), 0, stream, a);
+    GN_DISPATCH(gn_fwd_kernel)
     return ddpm_check_launch("gn_forward");
 }
 
@@ -283,10 +368,7 @@ extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_
     GnArgs a;
     if (int rc = gn_prepare(a, d, "gn_backward")) return rc;
     DDPM_REQUIRE(d->dy, "gn_backward: null dy");
-    DDPM_REQUIRE(a.G == 0 || (a.dgamma && a.dbeta), "gn_backward: dgamma/dbeta required");
-    const int units = a.N * (a.C / a.SC);
-    const long long vecs = (long long)a.HW * (a.SC / 8);
-    if (vecs <= 128) hipLaunchKernelGGL(gn_bwd_kernel<64>, dim3(units), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(gn_bwd_kernel<256>, dim3(units), dim3(256), 0, stream, a);
+    DDPM_REQUIRE(a.part, "gn_backward: partial-sum workspace required");
+    GN_DISPATCH(gn_bwd_kernel)
     return ddpm_check_launch("gn_backward");
 }

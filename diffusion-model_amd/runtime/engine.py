@@ -169,6 +169,9 @@ class GradStore:
     def zero(self):
         self.flat.zero_()
 
+    def offset(self, name: str) -> int:
+        return self.layout[name][0]
+
     def __getitem__(self, name: str) -> Tensor:
         return self.views[name]
 
@@ -208,6 +211,7 @@ class UNetEngine:
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
+        self._reduce_tables: Dict[Tuple[int, int, int], Tuple[Tensor, int, int, int]] = {}
 
     # ------------------------------------------------------------------------------------------ helpers
     def _site_sizes(self, n: int, h: int, w: int) -> List[int]:
@@ -278,6 +282,35 @@ class UNetEngine:
         G = self.grads
         wc = self.wc
 
+        # two-stage reductions: backward kernels write per-image / per-workgroup partial sums into one workspace,
+        # a single pass at the end of backward folds them into the gradient buffer (no contended atomics)
+        part_entries: List[Tuple[int, int, int, int, int]] = []
+        part_cursor = [0]
+        part_ws: List[Optional[Tensor]] = [None]
+        rkey = (n, h, w)
+
+        first_time: List[Tuple[Tensor, int]] = []     # (separately allocated piece, its offset) until the total is known
+
+        def part_alloc(numel: int) -> Tuple[Tensor, int]:
+            off = part_cursor[0]
+            part_cursor[0] += (numel + 3) // 4 * 4
+            if rkey not in self._reduce_tables:         # first backward for this shape: sizes are being discovered
+                piece = torch.empty(numel, device=dev, dtype=torch.float32)
+                first_time.append((piece, off))
+                return piece, off
+            if part_ws[0] is None:
+                part_ws[0] = torch.empty(self._reduce_tables[rkey][3], device=dev, dtype=torch.float32)
+            return part_ws[0][off:off + numel], off
+
+        def gn_partials(c: int, norm: Optional[str], conv_name: Optional[str]) -> Tensor:
+            buf, off = part_alloc(n * 3 * c)
+            if norm:
+                part_entries.append((off, G.offset(norm + ".weight"), n, 3 * c, c))
+                part_entries.append((off + c, G.offset(norm + ".bias"), n, 3 * c, c))
+            if conv_name:
+                part_entries.append((off + 2 * c, G.offset(conv_name + ".bias"), n, 3 * c, c))
+            return buf
+
         def next_mask():
             if not use_drop:
                 return None
@@ -311,8 +344,7 @@ class UNetEngine:
                         assert res.g is None
                         res.g = dy
                     draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
-                                               G[norm + ".weight"] if norm else None, G[norm + ".bias"] if norm else None,
-                                               dbias=G[name + ".bias"], mask=out_mask, mask_scale=mscale)
+                                               gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
                     out.g = None
                     ops.conv_wgrad(kind, x0.v, draw, cout, G[name + ".weight"], x1=None if x1 is None else x1.v,
                                    in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
@@ -342,10 +374,15 @@ class UNetEngine:
             out = Var(y)
             if tape is not None:
                 def bwd():
-                    draw = ops.gn_act_backward(raw, out.g, gamma, beta, sp.groups, sp.act, stats, G[norm + ".weight"], G[norm + ".bias"],
+                    cch = raw.shape[3]
+                    draw = ops.gn_act_backward(raw, out.g, gamma, beta, sp.groups, sp.act, stats, gn_partials(cch, norm, None),
                                                mask=out_mask, mask_scale=mscale)
                     out.g = None
-                    ops.dwconv3x3_wgrad(xin.v, draw, G[name + ".weight"], G[name + ".bias"])
+                    nb = ops.dwconv3x3_wgrad_blocks(*xin.v.shape)
+                    buf, off = part_alloc(nb * 10 * cch)
+                    ops.dwconv3x3_wgrad(xin.v, draw, buf)
+                    part_entries.append((off, G.offset(name + ".weight"), nb, 10 * cch, 9 * cch))
+                    part_entries.append((off + 9 * cch, G.offset(name + ".bias"), nb, 10 * cch, cch))
                     assert xin.g is None
                     xin.g = ops.dwconv3x3(draw, wc.dw_flip[name], None)
                 tape.append(bwd)
@@ -426,16 +463,27 @@ class UNetEngine:
                 ops.conv_wgrad(K33, hfeat.v, dz, c_img, G[name + ".weight"])
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
             tape.append(bwd_head)
-            return out, (tape, out_holder)
+
+            def finish():
+                if rkey not in self._reduce_tables:
+                    tab = ops.reduce_table(part_entries, dev)
+                    self._reduce_tables[rkey] = (tab, len(part_entries), max(e[4] for e in part_entries), part_cursor[0])
+                    part_ws[0] = torch.empty(part_cursor[0], device=dev, dtype=torch.float32)
+                    for piece, off in first_time:
+                        part_ws[0][off:off + piece.numel()].copy_(piece)
+                tab, ne, mw, _ = self._reduce_tables[rkey]
+                ops.reduce_rows(part_ws[0], G.flat, tab, ne, mw)
+            return out, (tape, out_holder, finish)
         return out, None
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Replay the tape in reverse; returns {parameter name: fp32 gradient in torch layout}."""
-        tape, out_holder = ctx
+        tape, out_holder, finish = ctx
         self.grads.zero()
         out_holder.g = dout
         for fn in reversed(tape):
             fn()
+        finish()
         tape.clear()
         return {k: self.grads.to_torch_layout(k, p) for k, p in params.items()}

@@ -35,9 +35,14 @@ class ConvDesc(C.Structure):
 class GnDesc(C.Structure):
     _fields_ = [
         ("x", _vp), ("gamma", _vp), ("beta", _vp), ("res", _vp), ("mask", _vp), ("mask_scale", _f),
-        ("y", _vp), ("stats", _vp), ("dy", _vp), ("dgamma", _vp), ("dbeta", _vp), ("dbias", _vp),
+        ("y", _vp), ("stats", _vp), ("dy", _vp), ("part", _vp),
         ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f),
     ]
+
+
+class ReduceEntry(C.Structure):
+    _fields_ = [("src_off", _i64), ("dst_off", _i64), ("rows", C.c_int32), ("row_stride", C.c_int32), ("width", C.c_int32),
+                ("pad", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -64,7 +69,9 @@ _PROTOS = {
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
-    "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),
+    "ddpm_reduce_rows": ([_vp, _vp, _vp, _i, _i, _vp], _i),
     "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
     "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),
     "ddpm_spatial_sum": ([_vp, _vp, _i, _i, _i, _vp], _i),

@@ -76,22 +76,24 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
     if groups > 0 and stats is None:
         stats = torch.empty(n, groups, 2, device=x.device, dtype=torch.float32)
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
-                   y=hip.ptr(out), stats=hip.ptr(stats), dy=None, dgamma=None, dbeta=None, dbias=None, N=n, HW=h * w, C=c, G=groups,
+                   y=hip.ptr(out), stats=hip.ptr(stats), dy=None, part=None, N=n, HW=h * w, C=c, G=groups,
                    act=act, eps=eps)
     hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream())
     return out, stats
 
 
 def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int,
-                    stats: Optional[Tensor], dgamma: Optional[Tensor], dbeta: Optional[Tensor], *, dbias: Optional[Tensor] = None,
-                    mask: Optional[Tensor] = None, mask_scale: float = 1.0, out: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+                    stats: Optional[Tensor], part: Tensor, *, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
+                    out: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    """Returns dx.  part: fp32 [N][3][C] receives per-image partial sums (dgamma, dbeta, bias gradient)."""
     n, h, w, c = x.shape
     assert dy.shape == x.shape and dy.dtype == BF16 and dy.is_contiguous()
+    assert part.dtype == torch.float32 and part.numel() == n * 3 * c
     if out is None:
         out = torch.empty_like(x)
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=None, mask=hip.ptr(mask), mask_scale=mask_scale,
-                   y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), dgamma=hip.ptr(dgamma), dbeta=hip.ptr(dbeta),
-                   dbias=hip.ptr(dbias), N=n, HW=h * w, C=c, G=groups, act=act, eps=eps)
+                   y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), part=hip.ptr(part), N=n, HW=h * w, C=c, G=groups, act=act,
+                   eps=eps)
     hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream())
     return out
 
@@ -106,10 +108,31 @@ def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tens
     return out
 
 
-def dwconv3x3_wgrad(x: Tensor, dy: Tensor, dw9c: Tensor, db: Optional[Tensor]) -> None:
+def dwconv3x3_wgrad_blocks(n: int, h: int, w: int, c: int) -> int:
+    return hip.lib().ddpm_dwconv3x3_wgrad_blocks(n, h, w, c)
+
+
+def dwconv3x3_wgrad(x: Tensor, dy: Tensor, part: Tensor) -> None:
+    """part: fp32 [blocks][10][C] per-workgroup partial sums (taps 0..8 of dw, then db)."""
     n, h, w, c = x.shape
-    assert dy.shape == x.shape and dw9c.shape == (9, c)
-    hip.call("ddpm_dwconv3x3_wgrad", hip.ptr(x), hip.ptr(dy), hip.ptr(dw9c), hip.ptr(db), n, h, w, c, hip.stream())
+    assert dy.shape == x.shape and part.numel() == dwconv3x3_wgrad_blocks(n, h, w, c) * 10 * c
+    hip.call("ddpm_dwconv3x3_wgrad", hip.ptr(x), hip.ptr(dy), hip.ptr(part), n, h, w, c, hip.stream())
+
+
+def reduce_rows(src: Tensor, dst: Tensor, entries: Tensor, n_entries: int, max_width: int) -> None:
+    """dst[e.dst_off + j] += sum_r src[e.src_off + r*e.row_stride + j] for every entry (device table of ReduceEntry)."""
+    hip.call("ddpm_reduce_rows", hip.ptr(src), hip.ptr(dst), hip.ptr(entries), n_entries, max_width, hip.stream())
+
+
+def reduce_table(entries, device) -> Tensor:
+    """Device copy of a list of (src_off, dst_off, rows, row_stride, width) tuples."""
+    import numpy as np
+    arr = np.zeros((len(entries), 4), dtype=np.int64)
+    for i, (so, do, rows, stride, width) in enumerate(entries):
+        arr[i, 0], arr[i, 1] = so, do
+        arr[i, 2] = (rows & 0xFFFFFFFF) | (stride << 32)
+        arr[i, 3] = width
+    return torch.from_numpy(arr).to(device)
 
 
 def colsum(x: Tensor, out: Tensor, c: int) -> None:

@@ -118,9 +118,9 @@ typedef struct ddpm_gn_desc {
     void* y;                  /* forward: output; backward: dx */
     float* stats;             /* fp32 [N][G][2] = (mean, rstd): written by forward, read by backward */
     const void* dy;           /* backward: gradient w.r.t. the output (before `res` was added) */
-    float* dgamma;            /* backward: fp32 [C], accumulated (+=) */
-    float* dbeta;             /* backward: fp32 [C], accumulated (+=) */
-    float* dbias;             /* backward, optional: fp32 [C] += sum of dx over n,h,w (bias gradient of the producing conv) */
+    float* part;              /* backward: fp32 [N][3][C] per-image partial sums, every element written once:
+                               * [n][0] = dgamma, [n][1] = dbeta, [n][2] = sum of dx over h,w (bias gradient of the producing
+                               * conv).  Sum over n with ddpm_reduce_rows. */
     int N, HW, C, G;          /* G = 0: no normalisation, activation only */
     int act;
     float eps;
@@ -129,7 +129,7 @@ typedef struct ddpm_gn_desc {
 /* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:
  * constituent_blocks.py:68-73,83-88,169-174,182-187; conv_block.py:67-72,90-95,110-114; unets.py:80-85,162-167 */
 int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream);
-/* dx, dgamma, dbeta (and dbias) of the above. */
+/* dx and the per-image partial sums of dgamma, dbeta, dbias of the above (no atomics: deterministic). */
 int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
 
 /* ---- depthwise 3x3 convolution, stride 1, padding 1, NHWC bf16 (dwconv.hip) ---------------------- */
@@ -138,8 +138,16 @@ int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
  * Also computes the data-gradient when given the tap-flipped weights and no bias. */
 int ddpm_dwconv3x3_forward(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                            ddpm_stream_t stream);
-/* dw[9][C] += sum dy * shifted x ; db[C] += sum dy   (fp32, accumulated with atomics; caller zeroes) */
-int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* db, int N, int H, int W, int C, ddpm_stream_t stream);
+/* Per-workgroup partial sums of the depthwise weight/bias gradient: part[b][t][c], t = 0..8 the taps of
+ * dw (sum dy * shifted x), t = 9 the bias (sum dy); b < ddpm_dwconv3x3_wgrad_blocks(N,H,W,C).  Every element is written. */
+int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* part, int N, int H, int W, int C, ddpm_stream_t stream);
+int ddpm_dwconv3x3_wgrad_blocks(int N, int H, int W, int C);
+
+/* dst[e.dst_off + j] += sum_{r < e.rows} src[e.src_off + r * e.row_stride + j], j < e.width, for every entry: the second
+ * stage of the partial-sum reductions above, all layers in one launch.  entries: device array. */
+typedef struct ddpm_reduce_entry { int64_t src_off; int64_t dst_off; int32_t rows; int32_t row_stride; int32_t width; int32_t pad; } ddpm_reduce_entry;
+int ddpm_reduce_rows(const float* src, float* dst, const ddpm_reduce_entry* entries, int n_entries, int max_width,
+                     ddpm_stream_t stream);
 
 /* ---- weight gradient of the dense convolutions (conv_wgrad.hip) ---------------------------------- */
 

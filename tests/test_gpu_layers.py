@@ -41,10 +41,15 @@ def test_groupnorm_act_fwd_bwd(dev, n, c, h, g, act):
         xg = x.view(n, g, -1)
         torch.testing.assert_close(stats[..., 0].cpu(), xg.mean(-1), rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(stats[..., 1].cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-4)
-    dgam, dbet, dbias = (torch.zeros(c, device=dev) for _ in range(3))
+    part = torch.full((n, 3, c), float("nan"), device=dev)
     dx = ops.gn_act_backward(nhwc(x, dev), nhwc(gy, dev), gamma.to(dev) if g else None, beta.to(dev) if g else None, g, hip.ACT[act],
-                             stats, dgam if g else None, dbet if g else None, dbias=dbias, mask=bits(keep).to(dev), mask_scale=1 / 0.9)
+                             stats, part, mask=bits(keep).to(dev), mask_scale=1 / 0.9)
     assert_rel(nchw(dx), grads[0], 1.5e-2)
+    # second stage: sum the per-image partials with the table-driven reduction
+    out = torch.zeros(3 * c, device=dev)
+    tab = ops.reduce_table([(0, 0, n, 3 * c, c), (c, c, n, 3 * c, c), (2 * c, 2 * c, n, 3 * c, c)], dev)
+    ops.reduce_rows(part, out, tab, 3, c)
+    dgam, dbet, dbias = out[:c], out[c:2 * c], out[2 * c:]
     assert_rel(dbias.cpu(), grads[0].sum((0, 2, 3)), 2e-2)
     if g:
         assert_rel(dgam.cpu(), grads[1], 1e-2)
@@ -66,10 +71,12 @@ def test_depthwise_fwd_dgrad_wgrad(dev, n, c, h, w_):
     w9f = w.flip(2, 3).reshape(c, 9).t().contiguous().to(dev)
     dx = ops.dwconv3x3(nhwc(gy, dev), w9f, None)
     assert_rel(nchw(dx), gx)
-    dw, db = torch.zeros(9, c, device=dev), torch.zeros(c, device=dev)
-    ops.dwconv3x3_wgrad(nhwc(x, dev), nhwc(gy, dev), dw, db)
-    assert_rel(dw.t().reshape(c, 1, 3, 3).cpu(), gw, 5e-3)
-    assert_rel(db.cpu(), gb, 5e-3)
+    nb = ops.dwconv3x3_wgrad_blocks(n, h, w_, c)
+    part = torch.full((nb, 10, c), float("nan"), device=dev)
+    ops.dwconv3x3_wgrad(nhwc(x, dev), nhwc(gy, dev), part)
+    tot = part.sum(0)
+    assert_rel(tot[:9].t().reshape(c, 1, 3, 3).cpu(), gw, 5e-3)
+    assert_rel(tot[9].cpu(), gb, 5e-3)
 
 
 WG_CASES = [
