@@ -24,6 +24,7 @@ import torch  # noqa: E402
 import dm_amd_bootstrap  # noqa: E402,F401
 from dm_amd.losses.ELBO import ELBOLoss  # noqa: E402
 from dm_amd.neural_nets.denoise_models import ddpm as dm_ddpm, unets as dm_unets  # noqa: E402
+from dm_amd.optimizer import FusedAdam  # noqa: E402
 from dm_amd.runtime import graphs  # noqa: E402
 
 YAML = dict(stages_channels=[32, 64, 128, 256], expand_factor=2, drop_p=0.1, T=120, beta=0.25, t_embed_dim=32, activation="gelu",
@@ -77,6 +78,7 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--sample-batch", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam(capturable) instead of the fused flat Adam")
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -95,7 +97,7 @@ def main():
     m = build_model(dev, a.channels)
     m.train()
     crit = ELBOLoss("mse")
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, capturable=True)
+    opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=0) if not a.torch_adam else torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
     x0 = (torch.rand(a.batch, a.channels, a.size, a.size, device=dev) * 2 - 1)
 
     after = None
@@ -133,7 +135,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"DDPM train step, {a.size}x{a.size}x{a.channels} (FashionMNIST-shaped), batch {a.batch}/GPU, "
-                               f"stages [32,64,128,256], T=120, drop_p=0.1, Adam, gradient_accumulation_steps=1",
+                               f"stages [32,64,128,256], T=120, drop_p=0.1, Adam (lr 1e-3), gradient_accumulation_steps=1",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
         "final_loss": loss,
     }

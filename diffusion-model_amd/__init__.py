@@ -4,4 +4,4 @@ The directory name contains a hyphen, so it is imported under the alias ``dm_amd
 (see dm_amd_bootstrap.py at the repository root).  Module paths mirror the reference's:
 ``dm_amd.neural_nets.denoise_models.{ddpm,unets}``, ``dm_amd.losses.ELBO``.
 """
-__all__ = ["runtime", "neural_nets", "losses", "utils"]
+__all__ = ["runtime", "neural_nets", "losses", "optimizer", "utils"]

@@ -400,20 +400,18 @@ __global__ __launch_bounds__(256) void dropout_masks_kernel(unsigned char* __res
                                                              int nsites, long long total_bytes, unsigned thresh,
                                                              const unsigned long long* __restrict__ seed) {
     const unsigned long long sd = *seed;
+    // every site's byte range starts and ends on a multiple of 4, so a 4-byte word never straddles two sites
     for (long long i = (blockIdx.x * 256ll + threadIdx.x) * 4; i < total_bytes; i += (long long)gridDim.x * 256 * 4) {
-        // site of byte i: offsets is a short ascending table; linear scan (nsites <= a few dozen)
-        int s = 0;
-        while (s + 1 < nsites && offsets[s + 1] <= i) ++s;
+        int lo = 0, hi = nsites - 1;            // last site whose offset <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offsets[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long long rel = i - offsets[lo];
         unsigned word = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const long long bi = i + b;
-            int sb = s;
-            while (sb + 1 < nsites && offsets[sb + 1] <= bi) ++sb;
-            word |= dropout_keep8(sd, (unsigned)sb, (unsigned long long)(bi - offsets[sb]), thresh) << (8 * b);
-        }
-        if (i + 4 <= total_bytes) *(unsigned*)(bytes + i) = word;
-        else for (int b = 0; b < 4 && i + b < total_bytes; ++b) bytes[i + b] = (unsigned char)(word >> (8 * b));
+        for (int b = 0; b < 4; ++b) word |= dropout_keep8(sd, (unsigned)lo, (unsigned long long)(rel + b), thresh) << (8 * b);
+        *(unsigned*)(bytes + i) = word;
     }
 }
 

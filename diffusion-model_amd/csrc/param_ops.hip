@@ -1,0 +1,91 @@
+// Multi-tensor parameter plumbing, one launch each for the whole network:
+//   - remap: fp32 torch-layout parameters -> bf16/fp32 kernel-layout copies (forward and data-gradient forms of every
+//     convolution weight, tap-major depthwise weights), and fp32 kernel-layout gradients -> fp32 torch-layout gradients;
+//   - Adam (+ optional EMA) over one flat parameter buffer.
+// The 350 parameter tensors of the denoiser are far too small to deserve a kernel each.
+#include "common.h"
+#include "ddpm_hip.h"
+
+// A[s][r][k] (dense, dims S x R x K, zero outside r < Rv, k < Kv)  <->  B[r*a_r + k*a_k + off_s[s]]
+// Work is cut into chunks of REMAP_CHUNK elements of A; chunks[i] = {entry index, first element / REMAP_CHUNK}, so
+// every workgroup has the same amount of work whatever the mix of tensor sizes.
+#define REMAP_CHUNK 2048
+__global__ __launch_bounds__(256) void remap_kernel(const ddpm_remap_entry* __restrict__ entries, const int2* __restrict__ chunks,
+                                                     int to_a) {
+    const int2 ch = chunks[blockIdx.x];
+    const ddpm_remap_entry e = entries[ch.x];
+    const long long total = (long long)e.S * e.R * e.K;
+    const long long i0 = (long long)ch.y * REMAP_CHUNK;
+#pragma unroll
+    for (int u = 0; u < REMAP_CHUNK / 256; ++u) {
+        const long long i = i0 + u * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int k = (int)(i % e.K);
+        const long long sr = i / e.K;
+        const int r = (int)(sr % e.R), s = (int)(sr / e.R);
+        const bool valid = r < e.Rv && k < e.Kv;
+        const long long bi = (long long)r * e.a_r + (long long)k * e.a_k + e.off_s[s];
+        if (to_a) {
+            const float v = valid ? ((const float*)e.b)[bi] : 0.f;
+            if (e.a_bf16) ((bf16*)e.a)[i] = (bf16)v;
+            else ((float*)e.a)[i] = v;
+        } else if (valid) {
+            ((float*)e.b)[bi] = e.a_bf16 ? (float)((const bf16*)e.a)[i] : ((const float*)e.a)[i];
+        }
+    }
+}
+
+extern "C" int ddpm_remap_chunk_elems(void) { return REMAP_CHUNK; }
+
+extern "C" int ddpm_remap(const ddpm_remap_entry* entries, const int32_t* chunks, int n_chunks, int to_a, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(entries && chunks && n_chunks > 0, "remap: bad arguments");
+    hipLaunchKernelGGL(remap_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, entries, (const int2*)chunks, to_a);
+    return ddpm_check_launch("remap");
+}
+
+// Adam with bias correction (torch.optim.Adam semantics, weight_decay = L2 added to the gradient), plus an optional
+// exponential moving average ema = lerp(ema, p, 1 - ema_decay) of the updated parameters
+// (torch.optim.swa_utils.AveragedModel with get_ema_multi_avg_fn: its first update copies the parameters).  step: device int64, incremented here by the first thread.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, float* __restrict__ ema, long long n,
+                                                    const float* __restrict__ lr_ptr, float lr_host, float b1, float b2, float eps,
+                                                    float wd, float ema_decay, float grad_scale, long long* __restrict__ step) {
+    const long long st = *step + 1;
+    const float lr = lr_ptr ? *lr_ptr : lr_host;
+    const float c1 = 1.0f - powf(b1, (float)st), c2 = 1.0f - powf(b2, (float)st);
+    const float step_size = lr / c1, inv_sqrt_c2 = rsqrtf(c2);
+    const long long n4 = n / 4;
+    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        f32x4 pp = *(f32x4*)(p + q * 4), gg = *(const f32x4*)(g + q * 4), mm = *(f32x4*)(m + q * 4), vv = *(f32x4*)(v + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] * grad_scale + wd * pp[j];
+            mm[j] = b1 * mm[j] + (1.0f - b1) * gr;
+            vv[j] = b2 * vv[j] + (1.0f - b2) * gr * gr;
+            pp[j] -= step_size * mm[j] / (sqrtf(vv[j]) * inv_sqrt_c2 + eps);
+        }
+        *(f32x4*)(p + q * 4) = pp; *(f32x4*)(m + q * 4) = mm; *(f32x4*)(v + q * 4) = vv;
+        if (ema) {
+            f32x4 ee = *(f32x4*)(ema + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ee[j] = st == 1 ? pp[j] : ee[j] + (1.0f - ema_decay) * (pp[j] - ee[j]);
+            *(f32x4*)(ema + q * 4) = ee;
+        }
+    }
+}
+
+__global__ void bump_step_kernel(long long* step) { *step += 1; }
+
+extern "C" int ddpm_adam_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                              int64_t* step, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(p && g && m && v && step && n > 0 && n % 4 == 0, "adam: bad arguments (n must be a multiple of 4)");
+    long long gx = (n / 4 + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, stream, p, g, m, v, ema, (long long)n, lr_dev, lr, beta1, beta2, eps,
+                       weight_decay, ema_decay, grad_scale, (long long*)step);
+    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, stream, (long long*)step);
+    return ddpm_check_launch("adam");
+}

@@ -1,0 +1,108 @@
+"""Optimizer registry with the reference's names (optimizer/optimizer.py:3-8 there) plus FusedAdam: Adam (and, when
+asked, the trainer's EMA of the weights, base_trainer.py:102-106,278-282 there) as ONE HIP kernel over a flat buffer.
+
+torch.optim.Adam on this network costs ~700 small kernels per step (350 tensors); the denoiser's whole
+forward+backward is only a few hundred kernels, so the optimizer must not be a per-tensor loop either."""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+from torch import Tensor
+
+from ..runtime import hip
+from ..runtime.params import bump_weight_epoch
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (bias-corrected, L2 weight decay, no amsgrad) on a flat fp32 copy of the parameters.
+
+    On the first step every parameter is re-pointed to a view of one flat buffer (values preserved), so state_dict(),
+    .grad, DDP and EMA wrappers keep working on the same nn.Parameter objects.  The step counter and the learning
+    rate live in device memory: the step is capturable in a HIP graph and an LR scheduler can update the rate
+    with `set_lr` without re-capturing."""
+
+    def __init__(self, params: Iterable[Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 ema_decay: Optional[float] = None, **_ignored):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.ema_decay = ema_decay
+        self._flat = None
+
+    # -------------------------------------------------------------------------------------------------
+    def _params(self) -> List[Tensor]:
+        return [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+
+    def _flatten(self) -> None:
+        ps = self._params()
+        dev = ps[0].device
+        if not ps[0].is_cuda:
+            raise RuntimeError("FusedAdam runs on the HIP kernels only: parameters must live on an MI355X (cuda) device")
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self._flat, self._offs, self._total = flat, offs, total
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
+        self._g = torch.zeros_like(flat)
+        self._ema = flat.clone() if self.ema_decay is not None else None
+        self._step = torch.zeros(1, device=dev, dtype=torch.long)
+        self._lr = torch.full((1,), float(self.param_groups[0]["lr"]), device=dev, dtype=torch.float32)
+
+    def set_lr(self, lr: float) -> None:
+        for g in self.param_groups:
+            g["lr"] = lr
+        if self._flat is not None:
+            self._lr.fill_(lr)
+
+    def ema_parameters(self) -> List[Tensor]:
+        """Views of the EMA weights, in parameter order (None unless ema_decay was given)."""
+        ps = self._params()
+        return [self._ema[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]
+
+    def _flat_grad(self, ps: List[Tensor]) -> Tensor:
+        """The gradients as one flat tensor in this optimizer's layout: zero-copy when they already are views of such a
+        buffer (what the HIP engine's backward produces), otherwise gathered with one foreach copy."""
+        g0 = ps[0].grad
+        base = g0._base if g0 is not None else None
+        if base is not None and base.numel() == self._total and base.dtype == torch.float32 and base.is_contiguous():
+            ok = all(p.grad is not None and p.grad._base is base and p.grad.storage_offset() == base.storage_offset() + o
+                     and p.grad.is_contiguous() for p, o in zip(ps, self._offs))
+            if ok:
+                return base
+        dst = [self._g[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]
+        src = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
+        torch._foreach_copy_(dst, src)
+        return self._g
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._flat is None:
+            self._flatten()
+        ps = self._params()
+        g = self._flat_grad(ps)
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        hip.call("ddpm_adam_step", hip.ptr(self._flat), hip.ptr(g), hip.ptr(self._m), hip.ptr(self._v), hip.ptr(self._ema), self._total,
+                 hip.ptr(self._lr), float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]),
+                 float(self.ema_decay if self.ema_decay is not None else 0.0), float(grad_scale), hip.ptr(self._step), hip.stream())
+        bump_weight_epoch()               # the update happened outside torch's view: invalidate cached weight copies
+        return loss
+
+
+OPTIMIZERS = {
+    "adam": torch.optim.Adam,
+    "adamw": torch.optim.AdamW,
+    "nadam": torch.optim.NAdam,
+    "sgd": torch.optim.SGD,
+    "fused_adam": FusedAdam,
+}

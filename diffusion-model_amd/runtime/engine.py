@@ -22,6 +22,7 @@ import torch
 from torch import Tensor
 
 from . import hip, ops, pack
+from .params import GradStore, WeightCache
 
 BF16 = torch.bfloat16
 K33, K33S2, K11, KT22 = hip.CONV_3X3_S1, hip.CONV_3X3_S2, hip.CONV_1X1, hip.CONVT_2X2_S2
@@ -96,117 +97,12 @@ class UNetSpec:
         self.convs[d + "out_layers.2"] = K33
 
 
-def _as4d(kind: int, w: Tensor) -> Tensor:
-    return w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)     # nn.Linear weight -> 1x1 conv
-
-
-class WeightCache:
-    """bf16 kernel-layout copies of the convolution weights (forward and data-gradient forms)."""
-
-    def __init__(self, spec: UNetSpec):
-        self.spec = spec
-        self.fwd: Dict[str, Tensor] = {}
-        self.dgrad: Dict[str, Tensor] = {}
-        self.dw: Dict[str, Tensor] = {}
-        self.dw_flip: Dict[str, Tensor] = {}
-        self._ver: Dict[str, Tuple[int, int]] = {}
-
-    def refresh(self, params: Dict[str, Tensor], need_dgrad: bool, force: bool = False) -> None:
-        if force:
-            self._ver.clear()
-        for name, kind in self.spec.convs.items():
-            w = params[name + ".weight"]
-            key = (w.data_ptr(), w._version)
-            if self._ver.get(name) != key or (need_dgrad and name not in self.dgrad):
-                w4 = _as4d(kind, w.detach())
-                self.fwd[name] = pack.pack_fwd(kind, w4)
-                if need_dgrad:
-                    self.dgrad[name] = pack.pack_dgrad(kind, w4)
-                else:
-                    self.dgrad.pop(name, None)
-                self._ver[name] = key
-        for name in self.spec.dwconvs:
-            w = params[name + ".weight"]
-            key = (w.data_ptr(), w._version)
-            if self._ver.get(name) != key:
-                c = w.shape[0]
-                wd = w.detach()
-                self.dw[name] = wd.reshape(c, 9).t().contiguous()
-                self.dw_flip[name] = wd.flip(2, 3).reshape(c, 9).t().contiguous()
-                self._ver[name] = key
-
-
-class GradStore:
-    """fp32 gradient accumulators in kernel layout, carved from one flat zero-initialised buffer."""
-
-    def __init__(self, spec: UNetSpec, params: Dict[str, Tensor], device):
-        self.spec = spec
-        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
-        off = 0
-        for name, p in params.items():
-            base = name.rsplit(".", 1)[0]
-            if name.endswith(".weight") and base in spec.convs:
-                kind = spec.convs[base]
-                w4 = _as4d(kind, p)
-                if kind == KT22:
-                    ci, co = w4.shape[:2]
-                    shp = (4, co, ci)
-                else:
-                    co, ci = w4.shape[:2]
-                    shp = (w4.shape[2] * w4.shape[3], co, (ci + 15) // 16 * 16)
-            elif name.endswith(".weight") and base in spec.dwconvs:
-                shp = (9, p.shape[0])
-            else:
-                shp = tuple(p.shape)
-            n = 1
-            for s in shp:
-                n *= s
-            self.layout[name] = (off, shp)
-            off += (n + 3) // 4 * 4
-        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
-        self.views = {k: self.flat[o:o + _numel(s)].view(s) for k, (o, s) in self.layout.items()}
-
-    def zero(self):
-        self.flat.zero_()
-
-    def offset(self, name: str) -> int:
-        return self.layout[name][0]
-
-    def __getitem__(self, name: str) -> Tensor:
-        return self.views[name]
-
-    def to_torch_layout(self, name: str, like: Tensor) -> Tensor:
-        """Gradient of parameter `name` in the parameter's own (torch) layout, a fresh tensor."""
-        g = self.views[name]
-        base = name.rsplit(".", 1)[0]
-        if name.endswith(".weight") and base in self.spec.convs:
-            kind = self.spec.convs[base]
-            if kind == KT22:                                   # [a*2+b][co][ci] -> (ci, co, a, b)
-                ci, co = like.shape[:2]
-                return g.view(2, 2, co, ci).permute(3, 2, 0, 1).contiguous()
-            if like.dim() == 2:                                # nn.Linear
-                return g[0, :, :like.shape[1]].clone()
-            co, ci, kh, kw = like.shape
-            return g[:, :, :ci].reshape(kh, kw, co, ci).permute(2, 3, 0, 1).contiguous()
-        if name.endswith(".weight") and base in self.spec.dwconvs:
-            c = like.shape[0]
-            return g.t().reshape(c, 1, 3, 3).contiguous()
-        return g.clone()
-
-
-def _numel(shape) -> int:
-    n = 1
-    for s in shape:
-        n *= s
-    return n
-
-
 class UNetEngine:
     """Runs BaseUNet.forward / its backward on the HIP kernels for one device."""
 
     def __init__(self, spec: UNetSpec):
         self.spec = spec
-        self.wc = WeightCache(spec)
+        self.wc = WeightCache(spec.convs, spec.dwconvs)
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
@@ -268,10 +164,10 @@ class UNetEngine:
         if h % (1 << nst) or w % (1 << nst):
             raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
         dev = x.device
-        self.wc.refresh(params, need_dgrad=record, force=self.always_repack)
+        self.wc.refresh(params, dev, force=self.always_repack)
         if record:
             if self.grads is None or self.grads.flat.device != dev:
-                self.grads = GradStore(sp, params, dev)
+                self.grads = GradStore(sp.convs, sp.dwconvs, params, dev)
         tape: Optional[List[Callable[[], None]]] = [] if record else None
         use_drop = train and sp.drop_p > 0.0
         if use_drop and masks is None:
@@ -486,4 +382,4 @@ class UNetEngine:
             fn()
         finish()
         tape.clear()
-        return {k: self.grads.to_torch_layout(k, p) for k, p in params.items()}
+        return self.grads.unpack()

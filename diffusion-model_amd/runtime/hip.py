@@ -45,6 +45,11 @@ class ReduceEntry(C.Structure):
                 ("pad", C.c_int32)]
 
 
+class RemapEntry(C.Structure):
+    _fields_ = [("a", _vp), ("b", _vp), ("S", C.c_int32), ("R", C.c_int32), ("K", C.c_int32), ("Rv", C.c_int32), ("Kv", C.c_int32),
+                ("a_r", C.c_int32), ("a_k", C.c_int32), ("off_s", C.c_int32 * 9), ("a_bf16", C.c_int32), ("pad", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("kind", _i), ("N", _i), ("IH", _i), ("IW", _i),
@@ -72,6 +77,9 @@ _PROTOS = {
     "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),
     "ddpm_reduce_rows": ([_vp, _vp, _vp, _i, _i, _vp], _i),
+    "ddpm_remap": ([_vp, _vp, _i, _i, _vp], _i),
+    "ddpm_remap_chunk_elems": ([], _i),
+    "ddpm_adam_step": ([_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _vp, _vp], _i),
     "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
     "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),
     "ddpm_spatial_sum": ([_vp, _vp, _i, _i, _i, _vp], _i),

@@ -1,0 +1,181 @@
+"""Device-side bookkeeping of the denoiser's parameters: kernel-layout weight copies, gradient buffers and the remap
+tables that convert between those and the torch layouts the nn.Parameters keep (one kernel launch per direction).
+
+Layouts.  Forward weight copy  : bf16 [slices][CoutW][CinP]   (CoutW = Cout rounded up to 32, CinP = Cin to 16)
+          Data-gradient copy   : bf16 [slices][CinW][CoutP]   (rows = input channels; 3x3 stride-1 taps flipped)
+          Depthwise weights    : fp32 [9][C] and its tap-flipped twin
+          Gradients (kernel)   : fp32 [slices][Cout][CinP] / [4][Cout][Cin] / [9][C] / [C]
+          Gradients (torch)    : one flat fp32 buffer, each parameter's .grad is a view of it in the parameter's layout
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import hip
+
+K33, K33S2, K11, KT22 = hip.CONV_3X3_S1, hip.CONV_3X3_S2, hip.CONV_1X1, hip.CONVT_2X2_S2
+
+
+# Bumped by optimizers that update parameters with a raw kernel (which torch's per-tensor version counters cannot see),
+# so that cached kernel-layout weight copies are refreshed on the next forward.
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch() -> None:
+    _WEIGHT_EPOCH[0] += 1
+
+
+def _ru(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _entry(a: int, b: int, S, R, K, Rv, Kv, a_r, a_k, off_s: Sequence[int], a_bf16: bool) -> hip.RemapEntry:
+    e = hip.RemapEntry(a=a, b=b, S=S, R=R, K=K, Rv=Rv, Kv=Kv, a_r=a_r, a_k=a_k, a_bf16=int(a_bf16), pad=0)
+    for i in range(9):
+        e.off_s[i] = off_s[i] if i < len(off_s) else 0
+    return e
+
+
+def _to_device(entries: List[hip.RemapEntry], device) -> Tuple[Tensor, Tensor, int]:
+    """(entry table, chunk table, number of chunks) on the device"""
+    arr = (hip.RemapEntry * len(entries))(*entries)
+    t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    ce = hip.lib().ddpm_remap_chunk_elems()
+    chunks = []
+    for i, e in enumerate(entries):
+        n = e.S * e.R * e.K
+        chunks.extend((i, c) for c in range((n + ce - 1) // ce))
+    ct = torch.tensor(chunks, dtype=torch.int32).to(device)
+    return t, ct, len(chunks)
+
+
+def conv_dims(kind: int, w: Tensor) -> Tuple[int, int, int]:
+    """(Cout, Cin, taps) of a dense convolution / linear weight in torch layout."""
+    if kind == KT22:
+        return w.shape[1], w.shape[0], 4
+    kk = 1 if w.dim() == 2 else w.shape[2] * w.shape[3]
+    return w.shape[0], w.shape[1], kk
+
+
+class WeightCache:
+    """Kernel-layout copies of all convolution weights, refreshed by ONE remap launch."""
+
+    def __init__(self, convs: Dict[str, int], dwconvs: List[str]):
+        self.convs, self.dwconvs = convs, dwconvs
+        self.fwd: Dict[str, Tensor] = {}
+        self.dgrad: Dict[str, Tensor] = {}
+        self.dw: Dict[str, Tensor] = {}
+        self.dw_flip: Dict[str, Tensor] = {}
+        self._ptrs: Tuple[int, ...] = ()
+        self._vers: Tuple[int, ...] = ()
+        self._table = self._chunks = None
+        self._n = 0
+
+    def _build(self, params: Dict[str, Tensor], device) -> None:
+        entries: List[hip.RemapEntry] = []
+        for name, kind in self.convs.items():
+            w = params[name + ".weight"]
+            co, ci, kk = conv_dims(kind, w)
+            cow, cip, ciw, cop = _ru(co, 32), _ru(ci, 16), _ru(ci, 32), _ru(co, 16)
+            if name not in self.fwd:
+                self.fwd[name] = torch.zeros(kk, cow, cip, device=device, dtype=torch.bfloat16)
+                self.dgrad[name] = torch.zeros(kk, ciw, cop, device=device, dtype=torch.bfloat16)
+            ident = list(range(kk))
+            if kind == KT22:
+                entries.append(_entry(self.fwd[name].data_ptr(), w.data_ptr(), kk, cow, cip, co, ci, 4, co * 4, ident, True))
+                entries.append(_entry(self.dgrad[name].data_ptr(), w.data_ptr(), kk, ciw, cop, ci, co, co * 4, 4, ident, True))
+            else:
+                flip = [kk - 1 - s for s in range(kk)] if kind == K33 else ident
+                entries.append(_entry(self.fwd[name].data_ptr(), w.data_ptr(), kk, cow, cip, co, ci, ci * kk, kk, ident, True))
+                entries.append(_entry(self.dgrad[name].data_ptr(), w.data_ptr(), kk, ciw, cop, ci, co, kk, ci * kk, flip, True))
+        for name in self.dwconvs:
+            w = params[name + ".weight"]
+            c = w.shape[0]
+            if name not in self.dw:
+                self.dw[name] = torch.zeros(9, c, device=device, dtype=torch.float32)
+                self.dw_flip[name] = torch.zeros(9, c, device=device, dtype=torch.float32)
+            entries.append(_entry(self.dw[name].data_ptr(), w.data_ptr(), 9, 1, c, 1, c, 0, 9, list(range(9)), False))
+            entries.append(_entry(self.dw_flip[name].data_ptr(), w.data_ptr(), 9, 1, c, 1, c, 0, 9, [8 - s for s in range(9)], False))
+        self._table, self._chunks, self._n = _to_device(entries, device)
+
+    def refresh(self, params: Dict[str, Tensor], device, force: bool = False) -> None:
+        names = [n + ".weight" for n in self.convs] + [n + ".weight" for n in self.dwconvs]
+        ptrs = tuple(params[n].data_ptr() for n in names)
+        vers = (_WEIGHT_EPOCH[0],) + tuple(params[n]._version for n in names)
+        if ptrs != self._ptrs:
+            self._build(params, device)
+            self._ptrs, self._vers = ptrs, ()
+        if force or vers != self._vers:
+            hip.call("ddpm_remap", hip.ptr(self._table), hip.ptr(self._chunks), self._n, 1, hip.stream())
+            self._vers = vers
+
+
+class GradStore:
+    """fp32 gradient accumulators in kernel layout (one flat zero-initialised buffer) and their torch-layout image."""
+
+    def __init__(self, convs: Dict[str, int], dwconvs: List[str], params: Dict[str, Tensor], device):
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.tlayout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = toff = 0
+        recipe = []
+        for name, p in params.items():
+            base = name.rsplit(".", 1)[0]
+            n_t = p.numel()
+            if name.endswith(".weight") and base in convs:
+                kind = convs[base]
+                co, ci, kk = conv_dims(kind, p)
+                if kind == KT22:
+                    shp = (4, co, ci)
+                    recipe.append((off, toff, 4, co, ci, co, ci, 4, co * 4, list(range(4))))
+                else:
+                    cip = _ru(ci, 16)
+                    shp = (kk, co, cip)
+                    recipe.append((off, toff, kk, co, cip, co, ci, ci * kk, kk, list(range(kk))))
+            elif name.endswith(".weight") and base in dwconvs:
+                c = p.shape[0]
+                shp = (9, c)
+                recipe.append((off, toff, 9, 1, c, 1, c, 0, 9, list(range(9))))
+            else:
+                shp = (n_t,)
+                recipe.append((off, toff, 1, 1, n_t, 1, n_t, 0, 1, [0]))
+            n_k = 1
+            for s in shp:
+                n_k *= s
+            self.layout[name] = (off, shp)
+            self.tlayout[name] = (toff, tuple(p.shape))
+            off += _ru(n_k, 4)
+            toff += _ru(n_t, 4)
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.flat_t = torch.zeros(toff, device=device, dtype=torch.float32)
+        self.views = {k: self.flat[o:o + _numel(s)].view(s) for k, (o, s) in self.layout.items()}
+        fa, fb = self.flat.data_ptr(), self.flat_t.data_ptr()
+        entries = [_entry(fa + 4 * o, fb + 4 * t, S, R, K, Rv, Kv, a_r, a_k, offs, False) for (o, t, S, R, K, Rv, Kv, a_r, a_k, offs) in recipe]
+        self._table, self._chunks, self._n = _to_device(entries, device)
+
+    def zero(self):
+        self.flat.zero_()
+
+    def offset(self, name: str) -> int:
+        return self.layout[name][0]
+
+    def __getitem__(self, name: str) -> Tensor:
+        return self.views[name]
+
+    def unpack(self) -> Dict[str, Tensor]:
+        """kernel layout -> torch layout for all parameters in one launch; returns {name: gradient}.  The gradients are
+        views of ONE freshly allocated flat buffer (a copy of the staging buffer), so a caller - autograd's accumulation
+        step in particular - may keep them: the next backward pass will not overwrite them."""
+        hip.call("ddpm_remap", hip.ptr(self._table), hip.ptr(self._chunks), self._n, 0, hip.stream())
+        out = self.flat_t.clone()
+        return {k: out[o:o + _numel(shp)].view(shp) for k, (o, shp) in self.tlayout.items()}
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= s
+    return n

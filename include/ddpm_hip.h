@@ -174,6 +174,32 @@ int ddpm_spatial_sum(const void* x, float* out, int N, int HW, int C, ddpm_strea
 int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int nsites, int64_t total_bytes, float keep,
                        const uint64_t* seed, ddpm_stream_t stream);
 
+/* ---- multi-tensor parameter plumbing (param_ops.hip) ------------------------------------------- */
+
+/* One remapping job: dense A[s][r][k] (S x R x K; bf16 or fp32)  <->  fp32 B[r*a_r + k*a_k + off_s[s]] for r < Rv, k < Kv.
+ * to_a = 1 fills A from B (zeros outside the valid range): used to derive the kernel-layout weight copies from the
+ * torch-layout parameters (Conv2d OIHW, ConvTranspose2d IOHW, Linear out x in: base_trainer.py:118-130 keeps those as
+ * the stored format).  to_a = 0 scatters A into B: kernel-layout gradients -> torch-layout .grad tensors. */
+typedef struct ddpm_remap_entry {
+    void* a; void* b;
+    int32_t S, R, K, Rv, Kv;
+    int32_t a_r, a_k;
+    int32_t off_s[9];
+    int32_t a_bf16;
+    int32_t pad;
+} ddpm_remap_entry;
+/* chunks: device int32 pairs {entry index, first element of A / ddpm_remap_chunk_elems()} covering every entry. */
+int ddpm_remap(const ddpm_remap_entry* entries /* device */, const int32_t* chunks /* device */, int n_chunks, int to_a,
+               ddpm_stream_t stream);
+int ddpm_remap_chunk_elems(void);
+
+/* torch.optim.Adam step (optimizer/optimizer.py:3-8, base_trainer.py:229) over one flat fp32 buffer, optionally followed
+ * by the EMA update of base_trainer.py:102-106,278-282 (ema may be NULL).  lr_dev (device float) overrides lr when given.
+ * *step (device int64) is the number of steps taken so far and is incremented. */
+int ddpm_adam_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int64_t* step,
+                   ddpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
