@@ -31,7 +31,7 @@ struct ConvArgs {
 // Loads are issued in batches of STAGE_U per thread before any of them is consumed, so that each thread keeps
 // several 16-byte requests in flight (the tensors are mostly L2 / Infinity-Cache resident: latency, not bandwidth,
 // is what a one-load-at-a-time loop would pay).
-#define STAGE_U 4
+#define STAGE_U 8
 
 template <int WM, int WN, int NT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
@@ -85,28 +85,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int parts = (Cin - c0 >= CONV_CK) ? 4 : (Cin - c0) / 8;   // 16-byte pieces per row in this chunk
         const int ksteps = (parts + 1) / 2;
         __syncthreads();   // previous chunk fully consumed (and s_pl visible on the first trip)
-        // -- stage patch
+        // -- stage the patch AND the weight rows of this chunk in one batched round: every thread first issues all of
+        //    its global loads (up to STAGE_U x 16 B), then applies the fused input transforms and writes LDS.
         const bool src1 = c0 >= a.C0;
         const bf16* src = src1 ? a.in1 : a.in0;
         const int cs = src1 ? a.C1 : a.C0, cc = src1 ? c0 - a.C0 : c0;
         const bool xform = !src1 && (a.in_add || a.in_mask);
-        for (int base = tid; base < npix * 4; base += T * STAGE_U) {
+        const int n_patch = npix * 4, n_items = n_patch + ntaps * BN * 4;
+        for (int base = tid; base < n_items; base += T * STAGE_U) {
             bf16x8 v[STAGE_U];
             long long e[STAGE_U];
-            int pl[STAGE_U];
+            int pl[STAGE_U], ldst[STAGE_U];
 #pragma unroll
             for (int u = 0; u < STAGE_U; ++u) {
                 const int it = base + u * T;
-                const int p = it >> 2, part = it & 3;
-                pl[u] = (it < npix * 4 && part < parts) ? s_pl[p] : -1;
+                pl[u] = -1; ldst[u] = -1; e[u] = 0;
+                if (it < n_patch) {
+                    const int p = it >> 2, part = it & 3;
+                    if (part < parts) {
+                        pl[u] = s_pl[p];
+                        ldst[u] = p * CONV_RS + part * 16;
+                        e[u] = (long long)pl[u] * cs + cc + part * 8;
+                    }
+                } else if (it < n_items) {
+                    const int wi = it - n_patch;
+                    const int row = wi >> 2, part = wi & 3;
+                    if (part < parts) {
+                        const int j = row / BN, co = row - j * BN;
+                        pl[u] = -2;          // weight item
+                        ldst[u] = (int)(s_w - s_patch) + row * CONV_RS + part * 16;
+                        e[u] = ((long long)g.tap_slice[tap0 + j] * a.w_rows + co0 + co) * Cin + c0 + part * 8;
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < STAGE_U; ++u) {
-                const int part = (base + u * T) & 3;
-                e[u] = (long long)pl[u] * cs + cc + part * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
                 if (pl[u] >= 0) v[u] = *(const bf16x8*)(src + e[u]);
+                else if (pl[u] == -2) v[u] = *(const bf16x8*)(a.w + e[u]);
             }
             if (xform) {
 #pragma unroll
@@ -126,30 +143,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < STAGE_U; ++u) {
-                const int it = base + u * T;
-                const int p = it >> 2, part = it & 3;
-                if (it < npix * 4 && part < parts) *(bf16x8*)(s_patch + p * CONV_RS + part * 16) = v[u];
-            }
-        }
-        // -- stage weights: rows = (tap, out channel), 32 input channels each
-        for (int base = tid; base < ntaps * BN * 4; base += T * STAGE_U) {
-            bf16x8 v[STAGE_U];
-#pragma unroll
-            for (int u = 0; u < STAGE_U; ++u) {
-                const int it = base + u * T;
-                const int row = it >> 2, part = it & 3;
-                if (it < ntaps * BN * 4 && part < parts) {
-                    const int j = row / BN, co = row - j * BN;
-                    v[u] = *(const bf16x8*)(a.w + ((long long)g.tap_slice[tap0 + j] * a.w_rows + co0 + co) * Cin + c0 + part * 8);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_U; ++u) {
-                const int it = base + u * T;
-                const int row = it >> 2, part = it & 3;
-                if (it < ntaps * BN * 4 && part < parts) *(bf16x8*)(s_w + row * CONV_RS + part * 16) = v[u];
-            }
+            for (int u = 0; u < STAGE_U; ++u)
+                if (ldst[u] >= 0) *(bf16x8*)(s_patch + ldst[u]) = v[u];
         }
         __syncthreads();
         // -- MFMA over taps x k-steps

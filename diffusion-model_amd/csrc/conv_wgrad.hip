@@ -35,6 +35,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
+#define WG_U 6
+
 template <int NCO, int MAXI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int T = 256, BM = 128;
@@ -106,42 +108,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             s_po[p] = ok ? (n * g.OH + oh) * g.OW + ow : -1;
         }
         __syncthreads();
-        // -- stage the input patch (32 channels of this block's chunk)
-        for (int it = tid; it < npix * 4; it += T) {
-            const int p = it >> 2, part = it & 3;
-            if (part >= parts) continue;
-            const int pl = s_pl[p];
-            bf16x8 v;
+        // -- stage the input patch (32 channels of this block's chunk) and the dY tile (BM positions x 32*NCO output
+        //    channels, zero rows for masked positions) in one batched round: all global loads first, then LDS writes.
+        const int n_patch = npix * 4, n_items = n_patch + BM * NCO * 4;
+        const bool xform = !src1 && (a.in_add || a.in_mask);
+        for (int base = tid; base < n_items; base += T * WG_U) {
+            bf16x8 v[WG_U];
+            long long e[WG_U];
+            int pl[WG_U], ldst[WG_U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
-            if (pl >= 0) {
-                const long long e = (long long)pl * cs + cc + part * 8;
-                v = *(const bf16x8*)(src + e);
-                if (!src1) {
+            for (int u = 0; u < WG_U; ++u) {
+                const int it = base + u * T;
+                pl[u] = -1; ldst[u] = -1; e[u] = 0;
+                if (it < n_patch) {
+                    const int p = it >> 2, part = it & 3;
+                    if (part < parts) {
+                        pl[u] = s_pl[p];
+                        ldst[u] = p * CONV_RS + part * 16;
+                        e[u] = (long long)pl[u] * cs + cc + part * 8;
+                    }
+                } else if (it < n_items) {
+                    const int di = it - n_patch;
+                    const int p = di / (NCO * 4), part = di - p * (NCO * 4);
+                    const int po = s_po[p];
+                    const int co = co0 + part * 8;
+                    ldst[u] = (int)(s_dy - s_patch) + p * DYS + part * 16;
+                    if (po >= 0 && co + 8 <= a.dy_cs) { pl[u] = -2; e[u] = (long long)po * a.dy_cs + co; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+                if (pl[u] >= 0) v[u] = *(const bf16x8*)(src + e[u]);
+                else if (pl[u] == -2) v[u] = *(const bf16x8*)(a.dy + e[u]);
+            }
+            if (xform) {
+#pragma unroll
+                for (int u = 0; u < WG_U; ++u) {
+                    if (pl[u] < 0) continue;
+                    const int part = (base + u * T) & 3;
                     if (a.in_add) {
-                        const float* ad = a.in_add + (pl / ihw) * a.C0 + cc + part * 8;
+                        const float* ad = a.in_add + (pl[u] / ihw) * a.C0 + cc + part * 8;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + ad[j]);
+                        for (int j = 0; j < 8; ++j) v[u][j] = (bf16)((float)v[u][j] + ad[j]);
                     }
                     if (a.in_mask) {
-                        const unsigned m = a.in_mask[e >> 3];
+                        const unsigned m = a.in_mask[e[u] >> 3];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.in_mask_scale) : (bf16)0.f;
+                        for (int j = 0; j < 8; ++j) v[u][j] = (m >> j) & 1 ? (bf16)((float)v[u][j] * a.in_mask_scale) : (bf16)0.f;
                     }
                 }
             }
-            *(bf16x8*)(s_patch + p * CONV_RS + part * 16) = v;
-        }
-        // -- stage the dY tile: BM positions x (32*NCO) output channels, zero rows for masked positions
-        for (int it = tid; it < BM * NCO * 4; it += T) {
-            const int p = it / (NCO * 4), part = it - p * (NCO * 4);
-            const int po = s_po[p];
-            const int co = co0 + part * 8;
-            bf16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
-            if (po >= 0 && co + 8 <= a.dy_cs) v = *(const bf16x8*)(a.dy + (long long)po * a.dy_cs + co);
-            *(bf16x8*)(s_dy + p * DYS + part * 16) = v;
+            for (int u = 0; u < WG_U; ++u)
+                if (ldst[u] >= 0) *(bf16x8*)(s_patch + ldst[u]) = v[u];
         }
         __syncthreads();
         // -- MFMA: for each of this wave's items, contract over the tile's 128 positions (8 k-steps of 16)

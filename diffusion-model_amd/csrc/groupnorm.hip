@@ -58,11 +58,13 @@ __device__ __forceinline__ void block_reduce_cols(float (&v)[8], int vps, float*
     }
 }
 
-// NV = vectors a thread keeps in registers when the whole slab fits (CACHED): the slab is then read from memory
-// exactly once, with all of a thread's loads in flight together; otherwise two passes with 4-way unrolled loops.
-#define GN_NV 8
+// NV = vectors a thread keeps in registers when the whole slab fits (NV > 0): the slab is then read from memory
+// exactly once, with all of a thread's loads in flight together; NV = 0 is the two-pass fallback for huge slabs.
+// Small NV with many threads is preferred: these kernels are latency bound, and a workgroup per image leaves a
+// CU with a single workgroup, so the waves must come from the workgroup size (up to 512 threads = 8 waves; 1024
+// threads would cap the kernel at 128 VGPRs and spill).
 
-template <int THREADS, bool CACHED>
+template <int THREADS, int NV>
 __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     __shared__ float s_red[(THREADS / 64) * 64 < 128 ? 128 : (THREADS / 64) * 64];
     __shared__ float s_mean[32], s_rstd[32];
@@ -74,6 +76,8 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
     const int cpg = a.G > 0 ? a.C / a.G : 1;
 
+    constexpr bool CACHED = NV > 0;
+    constexpr int GN_NV = NV > 0 ? NV : 1;
     bf16x8 xv[GN_NV];
     if constexpr (CACHED) {
 #pragma unroll
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
 // Backward.  With g = dy * mask * act'(z), xhat = (x - mean) rstd, m = cpg*HW:
 //   dgamma_c = sum g xhat,  dbeta_c = sum g,
 //   dx = rstd * ( gamma_c g - (S1 + xhat S2)/m ),  S1 = sum_group gamma g,  S2 = sum_group gamma g xhat.
-template <int THREADS, bool CACHED>
+template <int THREADS, int NV>
 __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
     __shared__ float s_red[(THREADS / 64) * 64 < 128 ? 128 : (THREADS / 64) * 64];
     __shared__ float s_s1[32], s_s2[32];
@@ -217,6 +221,8 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
             g[j] = (m >> j) & 1 ? gg : 0.f;
         }
     };
+    constexpr bool CACHED = NV > 0;
+    constexpr int GN_NV = NV > 0 ? NV : 1;
     bf16x8 xc[GN_NV], dc[GN_NV];
     if constexpr (CACHED) {
 #pragma unroll
@@ -334,7 +340,7 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     for (int c = 64; c >= 8; c >>= 1) {
         if (d->C % c || c % cpg || c / cpg > 32) continue;
         sc_min = c;
-        if (!sc && (long long)d->HW * (c / 8) <= 512 * GN_NV) sc = c;
+        if (!sc && (long long)d->HW * (c / 8) <= 4096) sc = c;
     }
     if (!sc) sc = sc_min;
     DDPM_REQUIRE(sc > 0, "%s: no slab width for C=%d, groups=%d", what, d->C, d->G);
@@ -345,15 +351,18 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     return DDPM_OK;
 }
 
-// Pick the workgroup size: the smallest of 64 / 256 / 512 threads whose registers can hold the whole slab
-// (GN_NV vectors per thread); slabs too large even for 512 threads take the two-pass path.
-#define GN_DISPATCH(KERNEL)                                                                                   \
-    const int units = a.N * (a.C / a.SC);                                                                     \
-    const long long vecs = (long long)a.HW * (a.SC / 8);                                                      \
-    if (vecs <= 64 * GN_NV) hipLaunchKernelGGL((KERNEL<64, true>), dim3(units), dim3(64), 0, stream, a);       \
-    else if (vecs <= 256 * GN_NV) hipLaunchKernelGGL((KERNEL<256, true>), dim3(units), dim3(256), 0, stream, a); \
-    else if (vecs <= 512 * GN_NV) hipLaunchKernelGGL((KERNEL<512, true>), dim3(units), dim3(512), 0, stream, a); \
-    else hipLaunchKernelGGL((KERNEL<512, false>), dim3(units), dim3(512), 0, stream, a);
+// Workgroup size / vectors per thread: aim for 2 vectors per thread (more waves, still two loads in flight each);
+// slabs beyond 1024 x 8 vectors take the two-pass path.
+#define GN_DISPATCH(KERNEL)                                                                                          \
+    const int units = a.N * (a.C / a.SC);                                                                            \
+    const long long vecs = (long long)a.HW * (a.SC / 8);                                                             \
+    if (vecs <= 64) hipLaunchKernelGGL((KERNEL<64, 1>), dim3(units), dim3(64), 0, stream, a);                        \
+    else if (vecs <= 128) hipLaunchKernelGGL((KERNEL<64, 2>), dim3(units), dim3(64), 0, stream, a);                  \
+    else if (vecs <= 512) hipLaunchKernelGGL((KERNEL<256, 2>), dim3(units), dim3(256), 0, stream, a);                \
+    else if (vecs <= 1024) hipLaunchKernelGGL((KERNEL<512, 2>), dim3(units), dim3(512), 0, stream, a);               \
+    else if (vecs <= 2048) hipLaunchKernelGGL((KERNEL<512, 4>), dim3(units), dim3(512), 0, stream, a);               \
+    else if (vecs <= 4096) hipLaunchKernelGGL((KERNEL<512, 8>), dim3(units), dim3(512), 0, stream, a);               \
+    else hipLaunchKernelGGL((KERNEL<512, 0>), dim3(units), dim3(512), 0, stream, a);
 
 extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
