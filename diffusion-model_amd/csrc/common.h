@@ -28,9 +28,22 @@ int ddpm_check_launch(const char* what);
         }                                        \
     } while (0)
 
+// erf via Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, i.e. fp32-level): one exp, one reciprocal, a 5-term
+// polynomial.  The exact-erf GELU (torch GELU(approximate="none"), the reference's default activation) is evaluated
+// for every element of ~80 tensors per pass, so its instruction count matters; and since erf(z/sqrt2) needs
+// exp(-z^2/2), the Gaussian factor of GELU's derivative comes for free.
+__device__ __forceinline__ void gelu_parts(float z, float& cdf, float& gauss) {
+    const float x = fabsf(z) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * x);
+    gauss = __expf(-x * x);                                   // exp(-z^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * gauss;
+    cdf = 0.5f * (1.0f + (z < 0.f ? -erf_abs : erf_abs));
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
     switch (act) {
-        case ACT_GELU: return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));
+        case ACT_GELU: { float c, g; gelu_parts(z, c, g); return z * c; }
         case ACT_SILU: return z / (1.0f + __expf(-z));
         case ACT_RELU: return z > 0.f ? z : 0.f;
         case ACT_TANH: return tanhf(z);
@@ -42,11 +55,7 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
 // d act(z) / dz
 __device__ __forceinline__ float act_bwd(float z, int act) {
     switch (act) {
-        case ACT_GELU: {
-            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
-            const float pdf = 0.39894228040143268f * __expf(-0.5f * z * z);
-            return cdf + z * pdf;
-        }
+        case ACT_GELU: { float c, g; gelu_parts(z, c, g); return c + z * 0.39894228040143268f * g; }
         case ACT_SILU: {
             const float s = 1.0f / (1.0f + __expf(-z));
             return s * (1.0f + z * (1.0f - s));

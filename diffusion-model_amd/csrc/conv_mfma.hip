@@ -75,10 +75,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int b_base = (wave_n * BNW + (lane & 31)) * CONV_RS + (lane >> 5) * 16;
 
     f32x16 acc[NT];
+    float bias_r[NT];                 // this lane's output-channel biases, fetched now so the epilogue does not wait for them
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+        const int co = co0 + wave_n * BNW + i * 32 + (lane & 31);
+        bias_r[i] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
 
     const int ihw = g.IH * g.IW;
     for (int c0 = 0; c0 < Cin; c0 += CONV_CK) {
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = co0 + wave_n * BNW + nt * 32 + (lane & 31);
-            const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+            const float b = bias_r[nt];
             float run = 0.f;
             int run_n = -1;
 #pragma unroll
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int co = co0 + wave_n * BNW + nt * 32 + (lane & 31);
             if (co >= a.Cout) continue;
-            const float b = a.bias ? a.bias[co] : 0.f;
+            const float b = bias_r[nt];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = wave_n * BNW + nt * 32 + (lane & 31);
-        const float b = (a.bias && co0 + col < a.Cout) ? a.bias[co0 + col] : 0.f;
+        const float b = bias_r[nt];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

@@ -78,6 +78,13 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
 
     constexpr bool CACHED = NV > 0;
     constexpr int GN_NV = NV > 0 ? NV : 1;
+    // per-channel affine parameters are fetched up front so their latency overlaps the slab loads
+    float gam[8], bet[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        gam[j] = a.G > 0 ? a.gamma[c0 + cv * 8 + j] : 1.f;
+        bet[j] = a.G > 0 ? a.beta[c0 + cv * 8 + j] : 0.f;
+    }
     bf16x8 xv[GN_NV];
     if constexpr (CACHED) {
 #pragma unroll
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     for (int j = 0; j < 8; ++j) {
         if (a.G > 0) {
             const int cl = cv * 8 + j, g = cl / cpg;
-            const float ga = a.gamma[c0 + cl] * s_rstd[g];
-            sc[j] = ga; sh[j] = a.beta[c0 + cl] - s_mean[g] * ga;
+            const float ga = gam[j] * s_rstd[g];
+            sc[j] = ga; sh[j] = bet[j] - s_mean[g] * ga;
         } else {
             sc[j] = 1.f; sh[j] = 0.f;
         }
@@ -221,10 +228,19 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
             g[j] = (m >> j) & 1 ? gg : 0.f;
         }
     };
+    // cached path: x stays in registers as bf16, the activation-gradient term g as fp32 (so exp/erf run once)
     constexpr bool CACHED = NV > 0;
     constexpr int GN_NV = NV > 0 ? NV : 1;
-    bf16x8 xc[GN_NV], dc[GN_NV];
+    bf16x8 xc[GN_NV];
+    float gc[GN_NV][8];
+    float S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) S1[j] = S2[j] = 0.f;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
     if constexpr (CACHED) {
+        bf16x8 dc[GN_NV];
 #pragma unroll
         for (int k = 0; k < GN_NV; ++k) {
             const int p = prow + k * pstep;
@@ -235,35 +251,29 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
                 dc[k] = *(const bf16x8*)(a.dy + base + (long long)p * a.C);
             }
         }
-    }
-    float S1[8], S2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) S1[j] = S2[j] = 0.f;
-    if (a.G > 0) {
-        float a1[8], a2[8];
+        for (int k = 0; k < GN_NV; ++k) {
+            const int p = prow + k * pstep;
+            float xh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
-        if constexpr (CACHED) {
+            for (int j = 0; j < 8; ++j) gc[k][j] = 0.f;
+            if (p < a.HW) {
+                gx(xc[k], dc[k], base + (long long)p * a.C, gc[k], xh);
 #pragma unroll
-            for (int k = 0; k < GN_NV; ++k) {
-                const int p = prow + k * pstep;
-                if (p < a.HW) {
-                    float g[8], xh[8];
-                    gx(xc[k], dc[k], base + (long long)p * a.C, g, xh);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
-                }
-            }
-        } else {
-#pragma unroll 2
-            for (int p = prow; p < a.HW; p += pstep) {
-                const long long e = base + (long long)p * a.C;
-                float g[8], xh[8];
-                gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
+                for (int j = 0; j < 8; ++j) { a1[j] += gc[k][j]; a2[j] += gc[k][j] * xh[j]; }
             }
         }
+    } else if (a.G > 0) {
+#pragma unroll 2
+        for (int p = prow; p < a.HW; p += pstep) {
+            const long long e = base + (long long)p * a.C;
+            float g[8], xh[8];
+            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
+        }
+    }
+    if (a.G > 0) {
         block_reduce_cols<THREADS>(a1, vps, s_red, tid);
         block_reduce_cols<THREADS>(a2, vps, s_red, tid);
         __syncthreads();
@@ -295,29 +305,36 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
     float db[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) db[j] = 0.f;
-    auto emit = [&](const bf16x8& xv, const bf16x8& dv, long long e) {
-        float g[8], xh[8];
-        gx(xv, dv, e, g, xh);
-        bf16x8 w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float dx = rstd[j] * (ga[j] * g[j] - (S1[j] + xh[j] * S2[j]));
-            db[j] += dx;
-            w[j] = (bf16)dx;
-        }
-        *(bf16x8*)(a.y + e) = w;
-    };
     if constexpr (CACHED) {
 #pragma unroll
         for (int k = 0; k < GN_NV; ++k) {
             const int p = prow + k * pstep;
-            if (p < a.HW) emit(xc[k], dc[k], base + (long long)p * a.C);
+            if (p < a.HW) {
+                bf16x8 w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xc[k][j] - mean[j]) * rstd[j];
+                    const float dx = rstd[j] * (ga[j] * gc[k][j] - (S1[j] + xh * S2[j]));
+                    db[j] += dx;
+                    w[j] = (bf16)dx;
+                }
+                *(bf16x8*)(a.y + base + (long long)p * a.C) = w;
+            }
         }
     } else {
 #pragma unroll 2
         for (int p = prow; p < a.HW; p += pstep) {
             const long long e = base + (long long)p * a.C;
-            emit(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e);
+            float g[8], xh[8];
+            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh);
+            bf16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dx = rstd[j] * (ga[j] * g[j] - (S1[j] + xh[j] * S2[j]));
+                db[j] += dx;
+                w[j] = (bf16)dx;
+            }
+            *(bf16x8*)(a.y + e) = w;
         }
     }
     block_reduce_cols<THREADS>(db, vps, s_red, tid);
@@ -340,7 +357,7 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     for (int c = 64; c >= 8; c >>= 1) {
         if (d->C % c || c % cpg || c / cpg > 32) continue;
         sc_min = c;
-        if (!sc && (long long)d->HW * (c / 8) <= 4096) sc = c;
+        if (!sc && (long long)d->HW * (c / 8) <= 2048) sc = c;
     }
     if (!sc) sc = sc_min;
     DDPM_REQUIRE(sc > 0, "%s: no slab width for C=%d, groups=%d", what, d->C, d->G);
