@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detail", default="", help="write a per-launch-shape timing table of the roofline pass to this file")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -162,7 +163,12 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         from dm_amd.runtime import roofline
-        out["roofline"] = roofline.measure(m, crit, a.batch, a.channels, a.size)
+        rows = [] if a.detail else None
+        out["roofline"] = roofline.measure(step._body, traffic_file=os.path.join(ROOT, "profiles", "hbm_traffic.json"), detail=rows)
+        if rows:
+            with open(a.detail, "w") as f:
+                for k, cnt, us, gbs, tf in sorted(rows, key=lambda r: -r[1] * r[2]):
+                    f.write(f"{k:60s} x{cnt:3d} {us:8.1f} us {gbs:8.1f} GB/s {tf:7.1f} TF/s  {cnt * us:8.1f} us/step\n")
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.channels, a.size, 64, 3)
     if rank == 0:

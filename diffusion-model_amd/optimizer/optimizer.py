@@ -11,7 +11,7 @@ import torch
 from torch import Tensor
 
 from ..runtime import hip
-from ..runtime.params import bump_weight_epoch
+from ..runtime.params import bump_weight_epoch, flat_grad_view
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -68,13 +68,9 @@ class FusedAdam(torch.optim.Optimizer):
     def _flat_grad(self, ps: List[Tensor]) -> Tensor:
         """The gradients as one flat tensor in this optimizer's layout: zero-copy when they already are views of such a
         buffer (what the HIP engine's backward produces), otherwise gathered with one foreach copy."""
-        g0 = ps[0].grad
-        base = g0._base if g0 is not None else None
-        if base is not None and base.numel() == self._total and base.dtype == torch.float32 and base.is_contiguous():
-            ok = all(p.grad is not None and p.grad._base is base and p.grad.storage_offset() == base.storage_offset() + o
-                     and p.grad.is_contiguous() for p, o in zip(ps, self._offs))
-            if ok:
-                return base
+        flat = flat_grad_view(ps, self._offs, self._total)
+        if flat is not None:
+            return flat
         dst = [self._g[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]
         src = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
         torch._foreach_copy_(dst, src)

@@ -22,7 +22,11 @@ class GraphedTrainStep:
     """randint t -> q -> UNet -> ELBO -> backward -> [grad hook, e.g. all-reduce] -> optimizer.step, as one graph.
 
     `x0` is a static input buffer: copy a new batch into `self.x0` before each `replay()`.
-    The optimizer must be capturable (torch.optim.Adam(..., capturable=True))."""
+    The optimizer must be capturable (FusedAdam, or torch.optim.Adam(..., capturable=True)).
+
+    With a gradient hook (data parallel) the step is captured as TWO graphs - everything up to the end of backward,
+    and the optimizer step - and the hook runs eagerly between them: the collective is one launch per step, and
+    keeping it out of the capture means the step does not depend on the collective library's graph support."""
 
     def __init__(self, ddpm, criterion, optimizer, x0: Tensor, *, after_backward: Optional[Callable[[], None]] = None,
                  use_graph: bool = True, warmup: int = 3):
@@ -40,13 +44,21 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream().wait_stream(s)
+        self.graph2 = None
         if use_graph:
             self.optimizer.zero_grad(set_to_none=True)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self._body()
+                self._front()
+                if self.after_backward is None:
+                    self._back()
+            if self.after_backward is not None:
+                self.after_backward()
+                self.graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph2):
+                    self._back()
 
-    def _body(self):
+    def _front(self):
         n = self.x0.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
         t = torch.randint(1, self.core.T + 1, (n,), device=self.x0.device)
@@ -54,16 +66,25 @@ class GraphedTrainStep:
         pred = self.ddpm(x_t, t)
         loss = self.criterion(self.ddpm, t, pred, self.x0, is_ddp=hasattr(self.ddpm, "module"))["Loss"]
         loss.backward()
-        if self.after_backward is not None:
-            self.after_backward()
-        self.optimizer.step()
         self.loss.copy_(loss.detach())
 
+    def _back(self):
+        self.optimizer.step()
+
+    def _body(self):
+        self._front()
+        if self.after_backward is not None:
+            self.after_backward()
+        self._back()
+
     def replay(self) -> Tensor:
-        if self.graph is not None:
-            self.graph.replay()
-        else:
+        if self.graph is None:
             self._body()
+        else:
+            self.graph.replay()
+            if self.graph2 is not None:
+                self.after_backward()
+                self.graph2.replay()
         return self.loss
 
 

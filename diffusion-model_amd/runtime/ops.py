@@ -11,6 +11,27 @@ from . import hip
 
 BF16 = torch.bfloat16
 
+# Launch probe (runtime.roofline installs one): an object whose .launch(kernel_name, cost_fn, fn) runs fn() between
+# two timing events on the launch stream; cost_fn() -> (algorithmic bytes, flops, shape tag) of that launch.  None in normal use.
+PROBE = None
+
+
+def _launch(kernel: str, cost, fn):
+    if PROBE is None:
+        fn()
+    else:
+        PROBE.launch(kernel, cost, fn)
+
+
+def _nb(*tensors) -> int:
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
+
+# MACs per output pixel and (input channel x output channel) pair
+_TAPS = {hip.CONV_3X3_S1: 9.0, hip.CONV_3X3_S2: 9.0, hip.CONV_1X1: 1.0, hip.CONVT_2X2_S2: 1.0, hip.DGRAD_3X3_S2: 2.25,
+         hip.DGRAD_CONVT_2X2: 4.0}
+_SLICES = {hip.CONV_3X3_S1: 9, hip.CONV_3X3_S2: 9, hip.CONV_1X1: 1, hip.CONVT_2X2_S2: 4, hip.DGRAD_3X3_S2: 9, hip.DGRAD_CONVT_2X2: 4}
+
 
 def conv_out_hw(kind: int, ih: int, iw: int):
     if kind in (hip.CONV_3X3_S1, hip.CONV_1X1):
@@ -48,7 +69,15 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      CoutW=(w.shape[1] if rows is None else (rows + 31) // 32 * 32), out_cs=(0 if f32_nchw else out.shape[3]),
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out))
-    hip.call("ddpm_conv_forward", C.byref(d), hip.stream())
+
+    def cost():
+        # every operand once: activations in, weight rows used, bias, epilogue operands, result
+        wbytes = _SLICES[kind] * d.CoutW * (c0 + c1) * 2
+        obytes = n * oh * ow * cout * (4 if f32_nchw else 2)
+        return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out) + wbytes + cout * 4 + obytes,
+                2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}")
+
+    _launch("conv_mfma_kernel", cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
     return out
 
 
@@ -61,7 +90,10 @@ def conv_wgrad(kind: int, x0: Tensor, dy: Tensor, cout: int, dw: Tensor, *, x1: 
     assert dw.shape[1] == cout and dw.shape[2] == c0 + c1, (tuple(dw.shape), cout, c0, c1)
     d = hip.WgradDesc(kind=kind, N=n, IH=ih, IW=iw, in0=hip.ptr(x0), in1=hip.ptr(x1), C0=c0, C1=c1, in_add=hip.ptr(in_add),
                       in_mask=hip.ptr(in_mask), in_mask_scale=in_scale, dy=hip.ptr(dy), Cout=cout, dy_cs=dy.shape[3], dw=hip.ptr(dw))
-    hip.call("ddpm_conv_wgrad", C.byref(d), hip.stream())
+    oh, ow = dy.shape[1], dy.shape[2]
+    _launch("conv_wgrad_kernel", lambda: (_nb(x0, x1, in_add, in_mask, dy, dw), 2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind],
+                                          f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}"),
+            lambda: hip.call("ddpm_conv_wgrad", C.byref(d), hip.stream()))
     return dw
 
 
@@ -78,7 +110,8 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=None, part=None, N=n, HW=h * w, C=c, G=groups,
                    act=act, eps=eps)
-    hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream())
+    _launch("gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
+            lambda: hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream()))
     return out, stats
 
 
@@ -94,7 +127,8 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=None, mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), part=hip.ptr(part), N=n, HW=h * w, C=c, G=groups, act=act,
                    eps=eps)
-    hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream())
+    _launch("gn_bwd_kernel", lambda: (_nb(x, dy, mask, out, gamma, beta, stats, part), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
+            lambda: hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream()))
     return out
 
 
@@ -104,7 +138,8 @@ def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tens
     assert x.dtype == BF16 and x.is_contiguous() and w9c.shape == (9, c) and w9c.dtype == torch.float32
     if out is None:
         out = torch.empty_like(x)
-    hip.call("ddpm_dwconv3x3_forward", hip.ptr(x), hip.ptr(w9c), hip.ptr(bias), hip.ptr(out), n, h, w, c, hip.stream())
+    _launch("dwconv3x3_kernel", lambda: (_nb(x, w9c, bias, out), 18.0 * x.numel(), f"{h}x{w} C{c}"),
+            lambda: hip.call("ddpm_dwconv3x3_forward", hip.ptr(x), hip.ptr(w9c), hip.ptr(bias), hip.ptr(out), n, h, w, c, hip.stream()))
     return out
 
 
@@ -116,7 +151,8 @@ def dwconv3x3_wgrad(x: Tensor, dy: Tensor, part: Tensor) -> None:
     """part: fp32 [blocks][10][C] per-workgroup partial sums (taps 0..8 of dw, then db)."""
     n, h, w, c = x.shape
     assert dy.shape == x.shape and part.numel() == dwconv3x3_wgrad_blocks(n, h, w, c) * 10 * c
-    hip.call("ddpm_dwconv3x3_wgrad", hip.ptr(x), hip.ptr(dy), hip.ptr(part), n, h, w, c, hip.stream())
+    _launch("dwconv3x3_wgrad_kernel", lambda: (_nb(x, dy, part), 20.0 * x.numel(), f"{h}x{w} C{c}"),
+            lambda: hip.call("ddpm_dwconv3x3_wgrad", hip.ptr(x), hip.ptr(dy), hip.ptr(part), n, h, w, c, hip.stream()))
 
 
 def reduce_rows(src: Tensor, dst: Tensor, entries: Tensor, n_entries: int, max_width: int) -> None:

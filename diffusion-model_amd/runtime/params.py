@@ -174,6 +174,24 @@ class GradStore:
         return {k: out[o:o + _numel(shp)].view(shp) for k, (o, shp) in self.tlayout.items()}
 
 
+def flat_grad_view(params: Sequence[Tensor], offs: Sequence[int], total: int):
+    """If the gradients of `params` all live in ONE fp32 allocation, parameter i at element offset offs[i] of a
+    `total`-element buffer (the layout GradStore.unpack produces), return that buffer as a flat tensor (zero-copy);
+    otherwise None.  autograd detaches the views it is handed, so the test is on storage identity and offsets."""
+    g0 = params[0].grad
+    if g0 is None or g0.dtype != torch.float32:
+        return None
+    st = g0.untyped_storage()
+    if st.nbytes() != total * 4:
+        return None
+    key = st.data_ptr()
+    for p, o in zip(params, offs):
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or g.untyped_storage().data_ptr() != key or g.storage_offset() != o or not g.is_contiguous():
+            return None
+    return torch.empty(0, device=g0.device, dtype=torch.float32).set_(st, 0, (total,))
+
+
 def _numel(shape) -> int:
     n = 1
     for s in shape:

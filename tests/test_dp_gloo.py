@@ -1,0 +1,76 @@
+"""Data-parallel gradient exchange on two CPU ranks (gloo): the flat-view fast path, the gather/scatter path, parameter
+broadcast and the sampling shard split.  Mirrors what the reference gets from accelerate's DDP wrapper
+(base_trainer.py:48-58,151-158 there): after the exchange every rank holds the mean gradient."""
+import os
+import socket
+
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+import dm_amd_bootstrap  # noqa: F401
+from dm_amd.runtime.dp import GradReducer, shard_range
+
+SHAPES = [(5, 3), (7,), (2, 3, 3, 3), (1,)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in SHAPES]
+        red = GradReducer(params, world, bucket_bytes=64)            # 16-element buckets: several collectives
+        red.broadcast_parameters()
+        sums = [p.detach().sum().item() for p in params]
+
+        # (1) gradients as views of one flat buffer, the layout the HIP engine's backward produces
+        flat = torch.zeros(red.total)
+        for p, o in zip(params, red.offs):
+            p.grad = flat[o:o + p.numel()].view(p.shape)
+            p.grad.fill_(float(rank + 1))
+        fv = red.flat_view()
+        assert fv is not None and fv.data_ptr() == flat.data_ptr() and len(red.buckets(fv)) > 1
+        red.allreduce()
+        ok1 = all(torch.allclose(p.grad, torch.full_like(p, (1 + world) / 2)) for p in params)
+
+        # (2) independent gradient tensors, one of them missing
+        for i, p in enumerate(params):
+            p.grad = None if i == 1 else torch.full_like(p, float(10 * (rank + 1) + i))
+        assert red.flat_view() is None
+        red.allreduce()
+        ok2 = all(torch.allclose(p.grad, torch.full_like(p, 0.0 if i == 1 else 10 * (1 + world) / 2 + i)) for i, p in enumerate(params))
+        q.put((rank, sums, ok1, ok2))
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1], "broadcast did not equalise the parameters"
+    assert all(r[2] and r[3] for r in res)
+
+
+def test_shard_range_covers_everything_once():
+    for total in (0, 1, 7, 256, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -268,3 +268,51 @@ def test_fused_adam_matches_torch_adam(dev):
     mc.load_state_dict(mb.state_dict())
     mc.eval()
     assert torch.equal(mb(x0, t), mc(x0, t))
+
+
+def test_graphed_train_step_with_gradient_hook(dev):
+    """The data-parallel step: graph (forward+backward) -> eager gradient hook -> graph (optimizer).  On one GPU the
+    hook is (a) a one-rank RCCL all-reduce through GradReducer's collective path, which must leave training intact, and
+    (b) a hook that zeroes the flat gradient buffer, after which Adam must not move the weights: proof that the hook
+    runs between the two graphs on the buffer the optimizer reads (zero-copy views of one flat gradient tensor)."""
+    import os
+    import torch.distributed as td
+    from dm_amd.optimizer import FusedAdam
+    from dm_amd.runtime import graphs
+    from dm_amd.runtime.dp import GradReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        crit = ELBOLoss("mse")
+        x0 = (hash_uniform((8, 1, 32, 32), 5) * 2 - 1).to(dev)
+        m, _, _ = build(dev, 1, "gelu", drop_p=0.1)
+        m.train()
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        red = GradReducer(list(m.parameters()), world=2)          # world=2 so that the collective path is taken
+        red.world = 1
+        seen = []
+
+        def hook():
+            flat = red.flat_view()
+            seen.append(flat is not None)
+            red._reduce(flat)
+
+        step = graphs.GraphedTrainStep(m, crit, opt, x0, after_backward=hook)
+        assert step.graph2 is not None
+        w0 = [p.detach().clone() for p in m.parameters()]
+        losses = [step.replay().item() for _ in range(4)]
+        assert all(seen) and all(math.isfinite(v) for v in losses)
+        moved = sum((p.detach() != w).any().item() for p, w in zip(m.parameters(), w0))
+        assert moved == len(w0)
+
+        m2, _, _ = build(dev, 1, "gelu", drop_p=0.1)
+        m2.train()
+        opt2 = FusedAdam(m2.parameters(), lr=1e-3)
+        red2 = GradReducer(list(m2.parameters()), world=1)
+        step2 = graphs.GraphedTrainStep(m2, crit, opt2, x0, after_backward=lambda: red2.flat_view().zero_())
+        w0 = [p.detach().clone() for p in m2.parameters()]
+        step2.replay(); step2.replay()
+        assert all(torch.equal(p.detach(), w) for p, w in zip(m2.parameters(), w0))
+    finally:
+        td.destroy_process_group()
