@@ -1,0 +1,426 @@
+// One SeparableInvertResidual block (conv_block.py:57-136 of the reference) as ONE kernel:
+//
+//     x --dropout--> 1x1 expand (C -> E=2C) -> GroupNorm -> act -> dropout
+//                 -> depthwise 3x3            -> GroupNorm -> act -> dropout
+//                 -> 1x1 project (E -> C)     -> GroupNorm -> (+ x)
+//
+// A workgroup owns whole images (one image, or 32/HW images when an image has fewer than 32 pixels, so that the
+// MFMA tile has 32 rows), which makes every GroupNorm statistic a workgroup-local reduction.  The activations of
+// the block never leave the CU: the block input and the expanded tensor live in LDS, the two pointwise
+// convolutions run on v_mfma_f32_32x32x16_bf16 with the weights streamed straight from L2 into registers (each
+// weight fragment is used by exactly one wave per workgroup), the depthwise stencil reads its neighbours from LDS.
+// Unfused, the same block is six launches with four HBM round trips of the expanded tensor; at these sizes
+// (<= 256 pixels x <= 512 channels per image) each of those launches is latency bound.
+//
+// In training the kernel also writes what the backward pass needs (raw convolution outputs, normalised
+// activations, statistics); in inference it writes only the block output.
+#include "common.h"
+#include "ddpm_hip.h"
+
+struct SirArgs {
+    const bf16* x;
+    bf16* y;
+    const bf16* we; const float* be; const float* g1; const float* b1;      // expand  [E][C] bf16
+    const float* wd; const float* bd; const float* g2; const float* b2;     // depthwise [9][E] fp32
+    const bf16* wp; const float* bp; const float* g3; const float* b3;      // project [C][E] bf16
+    const unsigned char* m_in; const unsigned char* m_e; const unsigned char* m_d;
+    float mscale;
+    bf16* raw_e; bf16* y_e; float* st1;
+    bf16* raw_d; bf16* y_d; float* st2;
+    bf16* raw_o; float* st3;
+    int N, act;
+    float eps;
+};
+
+constexpr int SIR_G = 16;            // GroupNorm groups (the reference's base_groups_norm * 4 default)
+constexpr int SIR_THREADS = 512;
+constexpr int SIR_SLOTS = 4 * (SIR_THREADS / 64);   // partial-sum slots: up to 4 passes x 8 waves
+
+template <int ACT>
+__device__ __forceinline__ float act_c(float z) {
+    if constexpr (ACT == ACT_GELU) { float c, g; gelu_parts(z, c, g); return z * c; }
+    else if constexpr (ACT == ACT_SILU) return z / (1.0f + __expf(-z));
+    else if constexpr (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
+    else return z;
+}
+
+// Shape bookkeeping of one elementwise phase over an [M][CH] bf16 tile: thread -> (row, 8-channel vector).
+template <int CH, int M>
+struct Ew {
+    static constexpr int VPR = CH / 8;                       // vectors per row
+    static constexpr int RPP = SIR_THREADS / VPR;            // rows per pass
+    static constexpr int NV = M * VPR / SIR_THREADS;         // vectors per thread
+    static constexpr int CPG = CH / SIR_G;                   // channels per group
+    static constexpr int GPV = CPG >= 8 ? 1 : 8 / CPG;       // groups inside one vector
+    static constexpr int VPG = CPG >= 8 ? CPG / 8 : 1;       // vectors spanning one group
+    static_assert(NV >= 1 && VPR <= 64 && (SIR_THREADS % VPR) == 0, "unsupported tile shape");
+};
+
+// Group statistics without atomics (bit-reproducible): every wave reduces the vectors it holds (all rows of a wave
+// belong to one image) and stores one partial per group into its own slot; the finalising threads add the slots of
+// their image in a fixed order.  Slot = pass * waves + wave when a workgroup holds several images (passes then
+// belong to different images), else just the wave (partials are accumulated over the passes first).
+template <int CH, int M>
+__device__ __forceinline__ void group_store(const float (&s)[8], const float (&ss)[8], int slot, int v, int lane, float* s_part) {
+    using E = Ew<CH, M>;
+    float a[E::GPV], b[E::GPV];
+#pragma unroll
+    for (int q = 0; q < E::GPV; ++q) {
+        a[q] = b[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8 / E::GPV; ++j) { a[q] += s[q * (8 / E::GPV) + j]; b[q] += ss[q * (8 / E::GPV) + j]; }
+    }
+#pragma unroll
+    for (int q = 0; q < E::GPV; ++q) {
+#pragma unroll
+        for (int o = 1; o < E::VPG; o <<= 1) { a[q] += __shfl_xor(a[q], o, 64); b[q] += __shfl_xor(b[q], o, 64); }
+#pragma unroll
+        for (int o = E::VPR; o < 64; o <<= 1) { a[q] += __shfl_xor(a[q], o, 64); b[q] += __shfl_xor(b[q], o, 64); }
+    }
+    if (lane < E::VPR && (v % E::VPG) == 0) {
+#pragma unroll
+        for (int q = 0; q < E::GPV; ++q) {
+            const int g = (v * 8) / E::CPG + q;
+            s_part[(slot * 2 + 0) * SIR_G + g] = a[q];
+            s_part[(slot * 2 + 1) * SIR_G + g] = b[q];
+        }
+    }
+}
+
+// mean / rstd of every (image, group) of the workgroup from the slots; thread t < IPW*16 owns (image t/16, group t%16).
+template <int CH, int M, int HW, int IPW>
+__device__ __forceinline__ void group_finish(int tid, const float* s_part, float* s_mr, float eps, float* st_out, long long n0, int N) {
+    using E = Ew<CH, M>;
+    constexpr int NWV = SIR_THREADS / 64;
+    if (tid < IPW * SIR_G) {
+        const int img = tid / SIR_G, g = tid % SIR_G;
+        float S = 0.f, SS = 0.f;
+        if constexpr (IPW == 1) {
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { S += s_part[(w * 2) * SIR_G + g]; SS += s_part[(w * 2 + 1) * SIR_G + g]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E::NV; ++k)
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) {
+                    const int slot_img = (w * (64 / E::VPR) + k * E::RPP) / HW;
+                    const float p = s_part[((k * NWV + w) * 2) * SIR_G + g], q = s_part[((k * NWV + w) * 2 + 1) * SIR_G + g];
+                    if (slot_img == img) { S += p; SS += q; }
+                }
+        }
+        const float im = 1.0f / (float)(E::CPG * HW);
+        const float mean = S * im;
+        const float var = fmaxf(SS * im - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        s_mr[tid * 2] = mean; s_mr[tid * 2 + 1] = rstd;
+        if (st_out && n0 + img < N) {
+            st_out[(n0 * SIR_G + tid) * 2] = mean;
+            st_out[(n0 * SIR_G + tid) * 2 + 1] = rstd;
+        }
+    }
+}
+
+// One 32x32 output tile of A[M][K] (LDS, row stride AS bytes) x B[N][K]^T (global bf16, row stride K elements).
+template <int K, int AS>
+__device__ __forceinline__ f32x16 gemm_tile(const char* s_a, int m0, const bf16* wrow /* row n0 + (lane & 31) */, int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int KS = K / 16, KCH = KS < 8 ? KS : 8;
+    const char* ap = s_a + (m0 + (lane & 31)) * AS + (lane >> 5) * 16;
+    const bf16* bp = wrow + (lane >> 5) * 8;
+#pragma unroll 1
+    for (int k0 = 0; k0 < KS; k0 += KCH) {
+        bf16x8 bv[KCH];
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) bv[u] = *(const bf16x8*)(bp + (k0 + u) * 16);
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+            const bf16x8 av = *(const bf16x8*)(ap + (k0 + u) * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[u], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+template <int C, int W, int ACT>
+__device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
+    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
+    constexpr int NWV = SIR_THREADS / 64;
+    using E1 = Ew<E, M>;
+    using E3 = Ew<C, M>;
+    char* s_x = smem;
+    char* s_e = smem + M * XS;
+    float* s_part = (float*)(s_e + M * ES);       // [slots][2][16] per-wave partial group sums / sums of squares
+    float* s_mr = s_part + SIR_SLOTS * 2 * SIR_G; // [IPW][16][2] mean, rstd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * IPW;
+    const long long row0 = (long long)n0 * HW;    // first global pixel row of this workgroup
+    const int rows_valid = min(M, (a.N - n0) * HW);
+    const bool rec = a.raw_e != nullptr;
+
+    // ---- block input -> LDS (dropout of the expansion input applied here; the residual re-reads the clean input)
+    for (int idx = tid; idx < M * (C / 8); idx += SIR_THREADS) {
+        const int row = idx / (C / 8), cv = idx % (C / 8);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+        if (row < rows_valid) {
+            const long long e = (row0 + row) * C + cv * 8;
+            v = *(const bf16x8*)(a.x + e);
+            if (a.m_in) {
+                const unsigned m = a.m_in[e >> 3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.mscale) : (bf16)0.f;
+            }
+        }
+        *(bf16x8*)(s_x + row * XS + cv * 16) = v;
+    }
+    __syncthreads();
+
+    // ---- expand: [M][C] x [E][C]^T -> raw_e (bf16) in LDS
+    {
+        constexpr int MT = M / 32, TT = MT * (E / 32);
+#pragma unroll 1
+        for (int t = wave; t < TT; t += NWV) {
+            const int mt = t % MT, nt = t / MT;
+            const int col = nt * 32 + (lane & 31);
+            const f32x16 acc = gemm_tile<C, XS>(s_x, mt * 32, a.we + (long long)col * C, lane);
+            const float b = a.be[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_e + row * ES + col * 2) = (bf16)(acc[r] + b);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- elementwise phases over the [M][E] tile ----------------------------------------------------------------
+    const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
+    bf16x8 xr[E1::NV];
+    // statistics of a raw tile held in xr[]; optional copy of the raw values to global memory
+    auto stats_phase = [&](bf16* raw_out, float* st_out) {
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) {
+            const int row = r1 + k * E1::RPP;
+            if (raw_out && row < rows_valid) *(bf16x8*)(raw_out + (row0 + row) * E + v1 * 8) = xr[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)xr[k][j]; s[j] += f; ss[j] += f * f; }
+            if constexpr (IPW > 1) {
+                group_store<E, M>(s, ss, k * NWV + wave, v1, lane, s_part);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+            }
+        }
+        if constexpr (IPW == 1) group_store<E, M>(s, ss, wave, v1, lane, s_part);
+        __syncthreads();
+        group_finish<E, M, HW, IPW>(tid, s_part, s_mr, a.eps, st_out, n0, a.N);
+        __syncthreads();
+    };
+    // normalise + activation + dropout of xr[] -> LDS tile (in place) and optionally global memory
+    auto apply_phase = [&](const float* gamma, const float* beta, const unsigned char* mask, bf16* y_out) {
+        float ga[8], be[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ga[j] = gamma[v1 * 8 + j]; be[j] = beta[v1 * 8 + j]; }
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) {
+            const int row = r1 + k * E1::RPP;
+            const int img = IPW > 1 ? row / HW : 0;
+            const long long e = (row0 + row) * E + v1 * 8;
+            unsigned m = 0xFFu;
+            if (mask && row < rows_valid) m = mask[e >> 3];
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = (v1 * 8 + j) / E1::CPG;
+                const float mean = s_mr[(img * SIR_G + g) * 2], rstd = s_mr[(img * SIR_G + g) * 2 + 1];
+                const float sc = ga[j] * rstd, sh = be[j] - mean * sc;
+                float z = act_c<ACT>((float)xr[k][j] * sc + sh);
+                if (mask) z = (m >> j) & 1 ? z * a.mscale : 0.f;
+                o[j] = (bf16)z;
+            }
+            *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
+            if (y_out && row < rows_valid) *(bf16x8*)(y_out + e) = o;
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) xr[k] = *(const bf16x8*)(s_e + (r1 + k * E1::RPP) * ES + v1 * 16);
+    stats_phase(rec ? a.raw_e : nullptr, rec ? a.st1 : nullptr);
+    apply_phase(a.g1, a.b1, a.m_e, rec ? a.y_e : nullptr);
+    __syncthreads();
+
+    // ---- depthwise 3x3 on the LDS tile -> xr[] (raw, bf16)
+    {
+        float acc[E1::NV][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float b = a.bd[v1 * 8 + j];
+#pragma unroll
+            for (int k = 0; k < E1::NV; ++k) acc[k][j] = b;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            float w[8];
+            const f32x4 w0 = *(const f32x4*)(a.wd + tap * E + v1 * 8), w1 = *(const f32x4*)(a.wd + tap * E + v1 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = w0[j]; w[4 + j] = w1[j]; }
+#pragma unroll
+            for (int k = 0; k < E1::NV; ++k) {
+                const int row = r1 + k * E1::RPP;
+                const int p = row % HW, py = p / W, px = p % W;
+                const int ny = py + dy, nx = px + dx;
+                if (ny >= 0 && ny < W && nx >= 0 && nx < W) {
+                    const bf16x8 nv = *(const bf16x8*)(s_e + (row + dy * W + dx) * ES + v1 * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[k][j] += (float)nv[j] * w[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[k][j] = (bf16)acc[k][j];
+    }
+    stats_phase(rec ? a.raw_d : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
+    apply_phase(a.g2, a.b2, a.m_d, rec ? a.y_d : nullptr);
+    __syncthreads();
+
+    // ---- project: [M][E] x [C][E]^T -> raw_o (bf16) into the LDS region of the (no longer needed) input tile
+    {
+        constexpr int MT = M / 32, TT = MT * (C / 32);
+#pragma unroll 1
+        for (int t = wave; t < TT; t += NWV) {
+            const int mt = t % MT, nt = t / MT;
+            const int col = nt * 32 + (lane & 31);
+            const f32x16 acc = gemm_tile<E, ES>(s_e, mt * 32, a.wp + (long long)col * E, lane);
+            const float b = a.bp[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_x + row * XS + col * 2) = (bf16)(acc[r] + b);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- last GroupNorm (no activation) + residual -> block output
+    {
+        const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
+        bf16x8 xo[E3::NV], rx[E3::NV];
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const int row = r3 + k * E3::RPP;
+            xo[k] = *(const bf16x8*)(s_x + row * XS + v3 * 16);
+            const long long e = (row0 + row) * C + v3 * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rx[k][j] = (bf16)0.f;
+            if (row < rows_valid) {
+                rx[k] = *(const bf16x8*)(a.x + e);
+                if (rec) *(bf16x8*)(a.raw_o + e) = xo[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
+            if constexpr (IPW > 1) {
+                group_store<C, M>(s, ss, k * NWV + wave, v3, lane, s_part);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+            }
+        }
+        if constexpr (IPW == 1) group_store<C, M>(s, ss, wave, v3, lane, s_part);
+        __syncthreads();
+        group_finish<C, M, HW, IPW>(tid, s_part, s_mr, a.eps, rec ? a.st3 : nullptr, n0, a.N);
+        __syncthreads();
+        float ga[8], be[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ga[j] = a.g3[v3 * 8 + j]; be[j] = a.b3[v3 * 8 + j]; }
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const int row = r3 + k * E3::RPP;
+            if (row >= rows_valid) continue;
+            const int img = IPW > 1 ? row / HW : 0;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = (v3 * 8 + j) / E3::CPG;
+                const float mean = s_mr[(img * SIR_G + g) * 2], rstd = s_mr[(img * SIR_G + g) * 2 + 1];
+                const float sc = ga[j] * rstd, sh = be[j] - mean * sc;
+                o[j] = (bf16)((float)xo[k][j] * sc + sh + (float)rx[k][j]);
+            }
+            *(bf16x8*)(a.y + (row0 + row) * C + v3 * 8) = o;
+        }
+    }
+}
+
+template <int C, int W>
+__global__ __launch_bounds__(SIR_THREADS) void sir_fwd_kernel(const SirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    switch (a.act) {
+        case ACT_GELU: sir_fwd_body<C, W, ACT_GELU>(a, smem); break;
+        case ACT_SILU: sir_fwd_body<C, W, ACT_SILU>(a, smem); break;
+        default: sir_fwd_body<C, W, ACT_RELU>(a, smem); break;
+    }
+}
+
+template <int C, int W>
+static int sir_launch(const SirArgs& a, hipStream_t stream) {
+    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) + (SIR_SLOTS * 2 * SIR_G + 2 * IPW * SIR_G) * 4;
+    static_assert(Ew<E, M>::NV <= 4 && Ew<C, M>::NV <= 4, "more passes than partial-sum slots");
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    auto k = sir_fwd_kernel<C, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            ddpm_set_error("sir_forward: cannot reserve %d bytes of LDS", lds);
+            return DDPM_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3((a.N + IPW - 1) / IPW), dim3(SIR_THREADS), lds, stream, a);
+    return ddpm_check_launch("sir_forward");
+}
+
+extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act) {
+    if (H != W || E != 2 * C || groups != SIR_G) return 0;
+    if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU) return 0;
+    return (C == 32 && W == 16) || (C == 64 && W == 8) || (C == 128 && W == 4) || (C == 256 && W == 2) ||
+           (C == 128 && W == 8) || (C == 256 && W == 4);
+}
+
+extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(d && d->x && d->y && d->we && d->be && d->g1 && d->b1 && d->wd && d->bd && d->g2 && d->b2 && d->wp && d->bp &&
+                     d->g3 && d->b3, "sir_forward: null pointer");
+    DDPM_REQUIRE(d->N > 0, "sir_forward: N must be positive");
+    DDPM_REQUIRE(ddpm_sir_supported(d->C, d->H, d->W, d->E, d->groups, d->act),
+                 "sir_forward: unsupported shape C=%d %dx%d E=%d groups=%d act=%d (use the unfused kernels)", d->C, d->H, d->W, d->E,
+                 d->groups, d->act);
+    const bool rec = d->raw_e != nullptr;
+    if (rec) DDPM_REQUIRE(d->y_e && d->st1 && d->raw_d && d->y_d && d->st2 && d->raw_o && d->st3, "sir_forward: incomplete set of saved-tensor pointers");
+    SirArgs a;
+    a.x = (const bf16*)d->x; a.y = (bf16*)d->y;
+    a.we = (const bf16*)d->we; a.be = d->be; a.g1 = d->g1; a.b1 = d->b1;
+    a.wd = d->wd; a.bd = d->bd; a.g2 = d->g2; a.b2 = d->b2;
+    a.wp = (const bf16*)d->wp; a.bp = d->bp; a.g3 = d->g3; a.b3 = d->b3;
+    a.m_in = d->m_in; a.m_e = d->m_e; a.m_d = d->m_d; a.mscale = d->mask_scale;
+    a.raw_e = (bf16*)d->raw_e; a.y_e = (bf16*)d->y_e; a.st1 = d->st1;
+    a.raw_d = (bf16*)d->raw_d; a.y_d = (bf16*)d->y_d; a.st2 = d->st2;
+    a.raw_o = (bf16*)d->raw_o; a.st3 = d->st3;
+    a.N = d->N; a.act = d->act; a.eps = d->eps;
+    if (d->C == 32 && d->W == 16) return sir_launch<32, 16>(a, stream);
+    if (d->C == 64 && d->W == 8) return sir_launch<64, 8>(a, stream);
+    if (d->C == 128 && d->W == 4) return sir_launch<128, 4>(a, stream);
+    if (d->C == 256 && d->W == 2) return sir_launch<256, 2>(a, stream);
+    if (d->C == 128 && d->W == 8) return sir_launch<128, 8>(a, stream);
+    return sir_launch<256, 4>(a, stream);
+}

@@ -106,6 +106,7 @@ class UNetEngine:
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
+        self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
         self._reduce_tables: Dict[Tuple[int, int, int], Tuple[Tensor, int, int, int]] = {}
 
@@ -234,32 +235,41 @@ class UNetEngine:
                                           mask=out_mask, mask_scale=mscale)
             out = Var(y)
             if tape is not None:
-                def bwd():
-                    dy = out.g
-                    if res is not None:                       # residual input receives the same gradient (no copy)
-                        assert res.g is None
-                        res.g = dy
-                    draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
-                                               gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
-                    out.g = None
-                    ops.conv_wgrad(kind, x0.v, draw, cout, G[name + ".weight"], x1=None if x1 is None else x1.v,
-                                   in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
-                    if not x0.need_grad:
-                        return                                  # network inputs (image, sinusoid) need no gradient
-                    wd = wc.dgrad[name]
-                    c0 = x0.v.shape[3]
-                    dk = pack.DGRAD_KIND[kind]
-                    # gradient of the broadcast add = per-image spatial sum of this conv's own data-gradient,
-                    # accumulated in fp32 inside the kernel (x0.g, added afterwards, belongs to other consumers)
-                    dsum = torch.zeros(n, c0, device=dev, dtype=torch.float32) if in_add is not None else None
-                    x0.g = ops.conv_forward(dk, draw, wd, None, c0, res=x0.g, out_mask=in_mask, out_scale=mscale, rows=c0, sum_out=dsum)
-                    if in_add is not None:
-                        in_add.g = dsum
-                    if x1 is not None:
-                        c1 = x1.v.shape[3]
-                        x1.g = ops.conv_forward(dk, draw, wd, None, c1, res=x1.g, row0=c0, rows=c1)
-                tape.append(bwd)
+                tape.append(conv_bwd(name, x0, x1, in_add, in_mask, raw, out, stats, norm, groups, act, res, out_mask))
             return out
+
+        def conv_bwd(name, x0, x1, in_add, in_mask, raw, out, stats, norm, groups, act, res, out_mask):
+            """backward of conv [-> GroupNorm] -> act [-> mask] [+ res] given what its forward saved"""
+            kind = sp.convs[name]
+            cout = P[name + ".bias"].shape[0]
+            gamma = P[norm + ".weight"] if norm else None
+            beta = P[norm + ".bias"] if norm else None
+
+            def bwd():
+                dy = out.g
+                if res is not None:                       # residual input receives the same gradient (no copy)
+                    assert res.g is None
+                    res.g = dy
+                draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
+                                           gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
+                out.g = None
+                ops.conv_wgrad(kind, x0.v, draw, cout, G[name + ".weight"], x1=None if x1 is None else x1.v,
+                               in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
+                if not x0.need_grad:
+                    return                                  # network inputs (image, sinusoid) need no gradient
+                wd = wc.dgrad[name]
+                c0 = x0.v.shape[3]
+                dk = pack.DGRAD_KIND[kind]
+                # gradient of the broadcast add = per-image spatial sum of this conv's own data-gradient,
+                # accumulated in fp32 inside the kernel (x0.g, added afterwards, belongs to other consumers)
+                dsum = torch.zeros(n, c0, device=dev, dtype=torch.float32) if in_add is not None else None
+                x0.g = ops.conv_forward(dk, draw, wd, None, c0, res=x0.g, out_mask=in_mask, out_scale=mscale, rows=c0, sum_out=dsum)
+                if in_add is not None:
+                    in_add.g = dsum
+                if x1 is not None:
+                    c1 = x1.v.shape[3]
+                    x1.g = ops.conv_forward(dk, draw, wd, None, c1, res=x1.g, row0=c0, rows=c1)
+            return bwd
 
         def dw_unit(pre: str, xin: Var, out_mask) -> Var:
             """depthwise 3x3 -> GroupNorm -> act [-> * out_mask]   (conv_block.py:77-96)"""
@@ -269,26 +279,49 @@ class UNetEngine:
             y, stats = ops.gn_act_forward(raw, gamma, beta, sp.groups, sp.act, mask=out_mask, mask_scale=mscale)
             out = Var(y)
             if tape is not None:
-                def bwd():
-                    cch = raw.shape[3]
-                    draw = ops.gn_act_backward(raw, out.g, gamma, beta, sp.groups, sp.act, stats, gn_partials(cch, norm, None),
-                                               mask=out_mask, mask_scale=mscale)
-                    out.g = None
-                    nb = ops.dwconv3x3_wgrad_blocks(*xin.v.shape)
-                    buf, off = part_alloc(nb * 10 * cch)
-                    ops.dwconv3x3_wgrad(xin.v, draw, buf)
-                    part_entries.append((off, G.offset(name + ".weight"), nb, 10 * cch, 9 * cch))
-                    part_entries.append((off + 9 * cch, G.offset(name + ".bias"), nb, 10 * cch, cch))
-                    assert xin.g is None
-                    xin.g = ops.dwconv3x3(draw, wc.dw_flip[name], None)
-                tape.append(bwd)
+                tape.append(dw_bwd(pre, xin, raw, out, stats, out_mask))
             return out
+
+        def dw_bwd(pre, xin, raw, out, stats, out_mask):
+            name, norm = pre + "depthwise.1", pre + "depthwise.2"
+            gamma, beta = P[norm + ".weight"], P[norm + ".bias"]
+
+            def bwd():
+                cch = raw.shape[3]
+                draw = ops.gn_act_backward(raw, out.g, gamma, beta, sp.groups, sp.act, stats, gn_partials(cch, norm, None),
+                                           mask=out_mask, mask_scale=mscale)
+                out.g = None
+                nb = ops.dwconv3x3_wgrad_blocks(*xin.v.shape)
+                buf, off = part_alloc(nb * 10 * cch)
+                ops.dwconv3x3_wgrad(xin.v, draw, buf)
+                part_entries.append((off, G.offset(name + ".weight"), nb, 10 * cch, 9 * cch))
+                part_entries.append((off + 9 * cch, G.offset(name + ".bias"), nb, 10 * cch, cch))
+                assert xin.g is None
+                xin.g = ops.dwconv3x3(draw, wc.dw_flip[name], None)
+            return bwd
 
         def sir(pre: str, xin: Var) -> Var:
             """SeparableInvertResidual (conv_block.py:132-136).  The three nn.Dropout sites act on the block input
             (fused into the expansion conv's loader) and on the two intermediate activations (fused into the
             GroupNorm epilogue that produces them)."""
             m_in, m_e, m_d = next_mask(), next_mask(), next_mask()
+            _, hh, ww, cc = xin.v.shape
+            ne, nd, npj = pre + "expansion.1", pre + "depthwise.1", pre + "projection.1"
+            ech = P[nd + ".bias"].shape[0]
+            if self.fuse_sir and ops.sir_supported(cc, hh, ww, ech, sp.groups, sp.act):
+                # whole block in one launch (activations resident in LDS); training saves what the per-unit backward needs
+                g1, g2, g3 = pre + "expansion.2", pre + "depthwise.2", pre + "projection.2"
+                y, sv = ops.sir_forward(xin.v, wc.fwd[ne], P[ne + ".bias"], P[g1 + ".weight"], P[g1 + ".bias"], wc.dw[nd], P[nd + ".bias"],
+                                        P[g2 + ".weight"], P[g2 + ".bias"], wc.fwd[npj], P[npj + ".bias"], P[g3 + ".weight"],
+                                        P[g3 + ".bias"], sp.groups, sp.act, masks=(m_in, m_e, m_d), mask_scale=mscale,
+                                        record=tape is not None)
+                out = Var(y)
+                if tape is not None:
+                    ev, dv = Var(sv["y_e"]), Var(sv["y_d"])
+                    tape.append(conv_bwd(ne, xin, None, None, m_in, sv["raw_e"], ev, sv["st1"], g1, sp.groups, sp.act, None, m_e))
+                    tape.append(dw_bwd(pre, ev, sv["raw_d"], dv, sv["st2"], m_d))
+                    tape.append(conv_bwd(npj, dv, None, None, None, sv["raw_o"], out, sv["st3"], g3, sp.groups, 0, xin, None))
+                return out
             e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
             d = dw_unit(pre, e, m_d)
             return conv_unit(pre + "projection.1", d, norm=pre + "projection.2", groups=sp.groups, act=0, res=xin)

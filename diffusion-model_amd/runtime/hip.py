@@ -40,6 +40,12 @@ class GnDesc(C.Structure):
     ]
 
 
+class SirDesc(C.Structure):
+    _fields_ = [(k, _vp) for k in ("x", "y", "we", "be", "g1", "b1", "wd", "bd", "g2", "b2", "wp", "bp", "g3", "b3", "m_in", "m_e", "m_d")] + [
+        ("mask_scale", _f), ("eps", _f)] + [(k, _vp) for k in ("raw_e", "y_e", "st1", "raw_d", "y_d", "st2", "raw_o", "st3")] + [
+        (k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act", "pad")]
+
+
 class ReduceEntry(C.Structure):
     _fields_ = [("src_off", _i64), ("dst_off", _i64), ("rows", C.c_int32), ("row_stride", C.c_int32), ("width", C.c_int32),
                 ("pad", C.c_int32)]
@@ -79,6 +85,8 @@ _PROTOS = {
     "ddpm_reduce_rows": ([_vp, _vp, _vp, _i, _i, _vp], _i),
     "ddpm_remap": ([_vp, _vp, _i, _i, _vp], _i),
     "ddpm_remap_chunk_elems": ([], _i),
+    "ddpm_sir_supported": ([_i, _i, _i, _i, _i, _i], _i),
+    "ddpm_sir_forward": ([_vp, _vp], _i),
     "ddpm_adam_step": ([_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _vp, _vp], _i),
     "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
     "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),

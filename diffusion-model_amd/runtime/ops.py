@@ -132,6 +132,42 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
     return out
 
 
+def sir_supported(c: int, h: int, w: int, e: int, groups: int, act: int) -> bool:
+    return bool(hip.lib().ddpm_sir_supported(c, h, w, e, groups, act))
+
+
+def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: Tensor, bd: Tensor, g2: Tensor, b2: Tensor,
+                wp: Tensor, bp: Tensor, g3: Tensor, b3: Tensor, groups: int, act: int, *, masks=(None, None, None),
+                mask_scale: float = 1.0, record: bool = False, eps: float = 1e-5):
+    """One fused SeparableInvertResidual block.  x: NHWC bf16 [N,H,W,C]; we: bf16 [1][E][C]; wd: fp32 [9][E]; wp: bf16 [1][C][E].
+    Returns (y, saved) where saved is None or the dict of tensors the backward pass needs
+    (raw_e, y_e, st1, raw_d, y_d, st2, raw_o, st3)."""
+    n, h, w, c = x.shape
+    e = wd.shape[1]
+    assert x.dtype == BF16 and x.is_contiguous() and we.dtype == BF16 and wp.dtype == BF16 and wd.dtype == torch.float32
+    assert we.shape[-2:] == (e, c) and wp.shape[-2:] == (c, e), (tuple(we.shape), tuple(wp.shape), e, c)
+    y = torch.empty_like(x)
+    saved = None
+    if record:
+        big = lambda: torch.empty(n, h, w, e, device=x.device, dtype=BF16)                        # noqa: E731
+        st = lambda: torch.empty(n, groups, 2, device=x.device, dtype=torch.float32)            # noqa: E731
+        saved = dict(raw_e=big(), y_e=big(), st1=st(), raw_d=big(), y_d=big(), st2=st(), raw_o=torch.empty_like(x), st3=st())
+    sv = saved or {}
+    d = hip.SirDesc(x=hip.ptr(x), y=hip.ptr(y), we=hip.ptr(we), be=hip.ptr(be), g1=hip.ptr(g1), b1=hip.ptr(b1), wd=hip.ptr(wd),
+                    bd=hip.ptr(bd), g2=hip.ptr(g2), b2=hip.ptr(b2), wp=hip.ptr(wp), bp=hip.ptr(bp), g3=hip.ptr(g3), b3=hip.ptr(b3),
+                    m_in=hip.ptr(masks[0]), m_e=hip.ptr(masks[1]), m_d=hip.ptr(masks[2]), mask_scale=mask_scale, eps=eps,
+                    raw_e=hip.ptr(sv.get("raw_e")), y_e=hip.ptr(sv.get("y_e")), st1=hip.ptr(sv.get("st1")),
+                    raw_d=hip.ptr(sv.get("raw_d")), y_d=hip.ptr(sv.get("y_d")), st2=hip.ptr(sv.get("st2")),
+                    raw_o=hip.ptr(sv.get("raw_o")), st3=hip.ptr(sv.get("st3")), N=n, C=c, H=h, W=w, E=e, groups=groups, act=act, pad=0)
+
+    def cost():
+        nb = _nb(x, y, we, wp, wd) + sum(_nb(t) for t in sv.values()) + sum(_nb(m) for m in masks)
+        return nb, 2.0 * n * h * w * (2 * c * e + 9 * e), f"{h}x{w} C{c} E{e}" + (" rec" if record else "")
+
+    _launch("sir_fwd_kernel", cost, lambda: hip.call("ddpm_sir_forward", C.byref(d), hip.stream()))
+    return y, saved
+
+
 def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
     """x: NHWC bf16; w9c: fp32 [9][C] tap-major."""
     n, h, w, c = x.shape

@@ -200,6 +200,30 @@ int ddpm_adam_step(float* p, const float* g, float* m, float* v, float* ema, int
                    float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int64_t* step,
                    ddpm_stream_t stream);
 
+/* One SeparableInvertResidual block (conv_block.py:57-136: dropout -> 1x1 expansion -> GroupNorm -> act -> dropout ->
+ * depthwise 3x3 -> GroupNorm -> act -> dropout -> 1x1 projection -> GroupNorm -> + input) as a single launch with the
+ * block's activations resident in LDS.  x, y: NHWC bf16 [N][H][W][C].  we: bf16 [E][C], wp: bf16 [C][E] (the forward
+ * weight-copy layout of ddpm_conv_forward), wd: fp32 [9][E]; biases and GroupNorm parameters fp32.  m_*: dropout keep
+ * bits of the three sites (1 byte per 8 consecutive NHWC elements), all NULL outside training.  The eight saved-tensor
+ * pointers are either all NULL (inference) or all given (training: raw convolution outputs, normalised activations
+ * after dropout, GroupNorm statistics [N][groups][2], exactly what the unfused kernels would have produced).
+ * Only the shapes for which ddpm_sir_supported() returns 1 are accepted. */
+typedef struct ddpm_sir_desc {
+    const void* x; void* y;
+    const void* we; const float* be; const float* g1; const float* b1;
+    const float* wd; const float* bd; const float* g2; const float* b2;
+    const void* wp; const float* bp; const float* g3; const float* b3;
+    const uint8_t* m_in; const uint8_t* m_e; const uint8_t* m_d;
+    float mask_scale;
+    float eps;
+    void* raw_e; void* y_e; float* st1;
+    void* raw_d; void* y_d; float* st2;
+    void* raw_o; float* st3;
+    int32_t N, C, H, W, E, groups, act, pad;
+} ddpm_sir_desc;
+int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act);
+int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
