@@ -34,20 +34,25 @@ int ddpm_check_launch(const char* what);
 // exp(-z^2/2), the Gaussian factor of GELU's derivative comes for free.
 __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& gauss) {
     const float x = fabsf(z) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * x);
-    gauss = __expf(-x * x);                                   // exp(-z^2/2)
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);          // v_rcp_f32 (1 ulp); an IEEE divide costs 11 instructions
+    gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);          // exp(-z^2/2) as one v_exp_f32
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * gauss;
     cdf = 0.5f * (1.0f + (z < 0.f ? -erf_abs : erf_abs));
 }
 
+// logistic function on the fast hardware exp2 / reciprocal (1-ulp) instructions
+__device__ __forceinline__ float sigmoid_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
     switch (act) {
         case ACT_GELU: { float c, g; gelu_parts(z, c, g); return z * c; }
-        case ACT_SILU: return z / (1.0f + __expf(-z));
+        case ACT_SILU: return z * sigmoid_fast(z);
         case ACT_RELU: return z > 0.f ? z : 0.f;
         case ACT_TANH: return tanhf(z);
-        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-z));
+        case ACT_SIGMOID: return sigmoid_fast(z);
         default: return z;
     }
 }
@@ -57,7 +62,7 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
     switch (act) {
         case ACT_GELU: { float c, g; gelu_parts(z, c, g); return c + z * 0.39894228040143268f * g; }
         case ACT_SILU: {
-            const float s = 1.0f / (1.0f + __expf(-z));
+            const float s = sigmoid_fast(z);
             return s * (1.0f + z * (1.0f - s));
         }
         case ACT_RELU: return z > 0.f ? 1.f : 0.f;
@@ -66,7 +71,7 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
             return 1.0f - t * t;
         }
         case ACT_SIGMOID: {
-            const float s = 1.0f / (1.0f + __expf(-z));
+            const float s = sigmoid_fast(z);
             return s * (1.0f - s);
         }
         default: return 1.f;

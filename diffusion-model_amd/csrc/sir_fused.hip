@@ -16,6 +16,7 @@
 // activations, statistics); in inference it writes only the block output.
 #include "common.h"
 #include "ddpm_hip.h"
+#include "sir_tile.h"
 
 struct SirArgs {
     const bf16* x;
@@ -32,29 +33,21 @@ struct SirArgs {
     float eps;
 };
 
-constexpr int SIR_G = 16;            // GroupNorm groups (the reference's base_groups_norm * 4 default)
-constexpr int SIR_THREADS = 512;
-constexpr int SIR_SLOTS = 4 * (SIR_THREADS / 64);   // partial-sum slots: up to 4 passes x 8 waves
-
-template <int ACT>
-__device__ __forceinline__ float act_c(float z) {
-    if constexpr (ACT == ACT_GELU) { float c, g; gelu_parts(z, c, g); return z * c; }
-    else if constexpr (ACT == ACT_SILU) return z / (1.0f + __expf(-z));
-    else if constexpr (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
-    else return z;
+// Diagnostic build only (-DSIR_STAMPS): lane 0 of every wave records the shader clock at phase boundaries into a
+// buffer of its own; no output value depends on it and the product build contains none of this.
+#ifdef SIR_STAMPS
+__device__ unsigned long long* sir_dbg = nullptr;
+extern "C" int ddpm_sir_set_dbg(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(sir_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -2;
 }
-
-// Shape bookkeeping of one elementwise phase over an [M][CH] bf16 tile: thread -> (row, 8-channel vector).
-template <int CH, int M>
-struct Ew {
-    static constexpr int VPR = CH / 8;                       // vectors per row
-    static constexpr int RPP = SIR_THREADS / VPR;            // rows per pass
-    static constexpr int NV = M * VPR / SIR_THREADS;         // vectors per thread
-    static constexpr int CPG = CH / SIR_G;                   // channels per group
-    static constexpr int GPV = CPG >= 8 ? 1 : 8 / CPG;       // groups inside one vector
-    static constexpr int VPG = CPG >= 8 ? CPG / 8 : 1;       // vectors spanning one group
-    static_assert(NV >= 1 && VPR <= 64 && (SIR_THREADS % VPR) == 0, "unsupported tile shape");
-};
+#define SIR_STAMP(i)                                                                                       \
+    do {                                                                                                   \
+        if (sir_dbg && (threadIdx.x & 63) == 0)                                                            \
+            sir_dbg[((unsigned long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SIR_STAMP(i)
+#endif
 
 // Group statistics without atomics (bit-reproducible): every wave reduces the vectors it holds (all rows of a wave
 // belong to one image) and stores one partial per group into its own slot; the finalising threads add the slots of
@@ -120,29 +113,6 @@ __device__ __forceinline__ void group_finish(int tid, const float* s_part, float
     }
 }
 
-// One 32x32 output tile of A[M][K] (LDS, row stride AS bytes) x B[N][K]^T (global bf16, row stride K elements).
-template <int K, int AS>
-__device__ __forceinline__ f32x16 gemm_tile(const char* s_a, int m0, const bf16* wrow /* row n0 + (lane & 31) */, int lane) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int KS = K / 16, KCH = KS < 8 ? KS : 8;
-    const char* ap = s_a + (m0 + (lane & 31)) * AS + (lane >> 5) * 16;
-    const bf16* bp = wrow + (lane >> 5) * 8;
-#pragma unroll 1
-    for (int k0 = 0; k0 < KS; k0 += KCH) {
-        bf16x8 bv[KCH];
-#pragma unroll
-        for (int u = 0; u < KCH; ++u) bv[u] = *(const bf16x8*)(bp + (k0 + u) * 16);
-#pragma unroll
-        for (int u = 0; u < KCH; ++u) {
-            const bf16x8 av = *(const bf16x8*)(ap + (k0 + u) * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[u], acc, 0, 0, 0);
-        }
-    }
-    return acc;
-}
-
 template <int C, int W, int ACT>
 __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
     constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
@@ -154,13 +124,46 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
     char* s_e = smem + M * XS;
     float* s_part = (float*)(s_e + M * ES);       // [slots][2][16] per-wave partial group sums / sums of squares
     float* s_mr = s_part + SIR_SLOTS * 2 * SIR_G; // [IPW][16][2] mean, rstd
+    float* s_p = s_mr + 2 * IPW * SIR_G;          // all per-channel parameters of the block, fetched once
+    constexpr int P_BE = 0, P_G1 = E, P_B1 = 2 * E, P_BD = 3 * E, P_G2 = 4 * E, P_B2 = 5 * E, P_WD = 6 * E, P_BP = 15 * E,
+                  P_G3 = 15 * E + C, P_B3 = 15 * E + 2 * C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * IPW;
     const long long row0 = (long long)n0 * HW;    // first global pixel row of this workgroup
     const int rows_valid = min(M, (a.N - n0) * HW);
     const bool rec = a.raw_e != nullptr;
 
-    // ---- block input -> LDS (dropout of the expansion input applied here; the residual re-reads the clean input)
+    SIR_STAMP(0);
+    // ---- everything small the block will need, requested now so that one memory round trip covers it all
+    for (int i = tid; i < E; i += SIR_THREADS) {
+        s_p[P_BE + i] = a.be[i]; s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i];
+        s_p[P_BD + i] = a.bd[i]; s_p[P_G2 + i] = a.g2[i]; s_p[P_B2 + i] = a.b2[i];
+    }
+    for (int i = tid; i < 9 * E; i += SIR_THREADS) s_p[P_WD + i] = a.wd[i];
+    for (int i = tid; i < C; i += SIR_THREADS) { s_p[P_BP + i] = a.bp[i]; s_p[P_G3 + i] = a.g3[i]; s_p[P_B3 + i] = a.b3[i]; }
+    const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
+    const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
+    unsigned mk_e[E1::NV], mk_d[E1::NV];
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) {
+        const int row = r1 + k * E1::RPP;
+        const long long e = (row0 + row) * E + v1 * 8;
+        mk_e[k] = mk_d[k] = 0xFFu;
+        if (a.m_e && row < rows_valid) { mk_e[k] = a.m_e[e >> 3]; mk_d[k] = a.m_d[e >> 3]; }
+    }
+    bf16x8 rx[E3::NV];                            // clean block input for the residual
+#pragma unroll
+    for (int k = 0; k < E3::NV; ++k) {
+        const int row = r3 + k * E3::RPP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[k][j] = (bf16)0.f;
+        if (row < rows_valid) rx[k] = *(const bf16x8*)(a.x + (row0 + row) * C + v3 * 8);
+    }
+    constexpr int MT = M / 32;
+    bf16x8 bfrag1[GemmK<C>::KCH];                 // first weight chunk of this wave's first expansion tile
+    if (wave < MT * (E / 32)) gemm_prefetch<C>(bfrag1, a.we + (long long)((wave / MT) * 32 + (lane & 31)) * C, lane);
+
+    // ---- block input -> LDS (dropout of the expansion input applied here; the residual uses the clean input)
     for (int idx = tid; idx < M * (C / 8); idx += SIR_THREADS) {
         const int row = idx / (C / 8), cv = idx % (C / 8);
         bf16x8 v;
@@ -178,16 +181,18 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         *(bf16x8*)(s_x + row * XS + cv * 16) = v;
     }
     __syncthreads();
+    SIR_STAMP(1);
 
     // ---- expand: [M][C] x [E][C]^T -> raw_e (bf16) in LDS
     {
-        constexpr int MT = M / 32, TT = MT * (E / 32);
+        constexpr int TT = MT * (E / 32);
 #pragma unroll 1
         for (int t = wave; t < TT; t += NWV) {
             const int mt = t % MT, nt = t / MT;
             const int col = nt * 32 + (lane & 31);
-            const f32x16 acc = gemm_tile<C, XS>(s_x, mt * 32, a.we + (long long)col * C, lane);
-            const float b = a.be[col];
+            if (t != wave) gemm_prefetch<C>(bfrag1, a.we + (long long)col * C, lane);
+            const f32x16 acc = gemm_tile<C, XS>(s_x, mt * 32, a.we + (long long)col * C, lane, bfrag1);
+            const float b = s_p[P_BE + col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -196,9 +201,9 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         }
     }
     __syncthreads();
+    SIR_STAMP(2);
 
     // ---- elementwise phases over the [M][E] tile ----------------------------------------------------------------
-    const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
     bf16x8 xr[E1::NV];
     // statistics of a raw tile held in xr[]; optional copy of the raw values to global memory
     auto stats_phase = [&](bf16* raw_out, float* st_out) {
@@ -223,7 +228,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         __syncthreads();
     };
     // normalise + activation + dropout of xr[] -> LDS tile (in place) and optionally global memory
-    auto apply_phase = [&](const float* gamma, const float* beta, const unsigned char* mask, bf16* y_out) {
+    auto apply_phase = [&](const float* gamma, const float* beta, bool mask, const unsigned (&mk)[E1::NV], bf16* y_out) {
         float ga[8], be[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ga[j] = gamma[v1 * 8 + j]; be[j] = beta[v1 * 8 + j]; }
@@ -232,8 +237,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
             const int row = r1 + k * E1::RPP;
             const int img = IPW > 1 ? row / HW : 0;
             const long long e = (row0 + row) * E + v1 * 8;
-            unsigned m = 0xFFu;
-            if (mask && row < rows_valid) m = mask[e >> 3];
+            const unsigned m = mk[k];
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -252,15 +256,17 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) xr[k] = *(const bf16x8*)(s_e + (r1 + k * E1::RPP) * ES + v1 * 16);
     stats_phase(rec ? a.raw_e : nullptr, rec ? a.st1 : nullptr);
-    apply_phase(a.g1, a.b1, a.m_e, rec ? a.y_e : nullptr);
+    SIR_STAMP(3);
+    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e != nullptr, mk_e, rec ? a.y_e : nullptr);
     __syncthreads();
+    SIR_STAMP(4);
 
     // ---- depthwise 3x3 on the LDS tile -> xr[] (raw, bf16)
     {
         float acc[E1::NV][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float b = a.bd[v1 * 8 + j];
+            const float b = s_p[P_BD + v1 * 8 + j];
 #pragma unroll
             for (int k = 0; k < E1::NV; ++k) acc[k][j] = b;
         }
@@ -268,7 +274,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             float w[8];
-            const f32x4 w0 = *(const f32x4*)(a.wd + tap * E + v1 * 8), w1 = *(const f32x4*)(a.wd + tap * E + v1 * 8 + 4);
+            const f32x4 w0 = *(const f32x4*)(s_p + P_WD + tap * E + v1 * 8), w1 = *(const f32x4*)(s_p + P_WD + tap * E + v1 * 8 + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { w[j] = w0[j]; w[4 + j] = w1[j]; }
 #pragma unroll
@@ -288,19 +294,25 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xr[k][j] = (bf16)acc[k][j];
     }
+    SIR_STAMP(5);
+    bf16x8 bfrag2[GemmK<E>::KCH];                 // first weight chunk of this wave's first projection tile
+    if (wave < MT * (C / 32)) gemm_prefetch<E>(bfrag2, a.wp + (long long)((wave / MT) * 32 + (lane & 31)) * E, lane);
     stats_phase(rec ? a.raw_d : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
-    apply_phase(a.g2, a.b2, a.m_d, rec ? a.y_d : nullptr);
+    SIR_STAMP(6);
+    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e != nullptr, mk_d, rec ? a.y_d : nullptr);
     __syncthreads();
+    SIR_STAMP(7);
 
     // ---- project: [M][E] x [C][E]^T -> raw_o (bf16) into the LDS region of the (no longer needed) input tile
     {
-        constexpr int MT = M / 32, TT = MT * (C / 32);
+        constexpr int TT = MT * (C / 32);
 #pragma unroll 1
         for (int t = wave; t < TT; t += NWV) {
             const int mt = t % MT, nt = t / MT;
             const int col = nt * 32 + (lane & 31);
-            const f32x16 acc = gemm_tile<E, ES>(s_e, mt * 32, a.wp + (long long)col * E, lane);
-            const float b = a.bp[col];
+            if (t != wave) gemm_prefetch<E>(bfrag2, a.wp + (long long)col * E, lane);
+            const f32x16 acc = gemm_tile<E, ES>(s_e, mt * 32, a.wp + (long long)col * E, lane, bfrag2);
+            const float b = s_p[P_BP + col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -309,11 +321,11 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         }
     }
     __syncthreads();
+    SIR_STAMP(8);
 
     // ---- last GroupNorm (no activation) + residual -> block output
     {
-        const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
-        bf16x8 xo[E3::NV], rx[E3::NV];
+        bf16x8 xo[E3::NV];
         float s[8], ss[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
@@ -322,12 +334,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
             const int row = r3 + k * E3::RPP;
             xo[k] = *(const bf16x8*)(s_x + row * XS + v3 * 16);
             const long long e = (row0 + row) * C + v3 * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) rx[k][j] = (bf16)0.f;
-            if (row < rows_valid) {
-                rx[k] = *(const bf16x8*)(a.x + e);
-                if (rec) *(bf16x8*)(a.raw_o + e) = xo[k];
-            }
+            if (rec && row < rows_valid) *(bf16x8*)(a.raw_o + e) = xo[k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
             if constexpr (IPW > 1) {
@@ -342,7 +349,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         __syncthreads();
         float ga[8], be[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ga[j] = a.g3[v3 * 8 + j]; be[j] = a.b3[v3 * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { ga[j] = s_p[P_G3 + v3 * 8 + j]; be[j] = s_p[P_B3 + v3 * 8 + j]; }
 #pragma unroll
         for (int k = 0; k < E3::NV; ++k) {
             const int row = r3 + k * E3::RPP;
@@ -359,6 +366,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
             *(bf16x8*)(a.y + (row0 + row) * C + v3 * 8) = o;
         }
     }
+    SIR_STAMP(9);
 }
 
 template <int C, int W>
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_fwd_kernel(const SirArgs a) {
 template <int C, int W>
 static int sir_launch(const SirArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
-    constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) + (SIR_SLOTS * 2 * SIR_G + 2 * IPW * SIR_G) * 4;
+    constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) + (SIR_SLOTS * 2 * SIR_G + 2 * IPW * SIR_G + 15 * E + 3 * C) * 4;
     static_assert(Ew<E, M>::NV <= 4 && Ew<C, M>::NV <= 4, "more passes than partial-sum slots");
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     auto k = sir_fwd_kernel<C, W>;

@@ -1,0 +1,472 @@
+// Backward of one SeparableInvertResidual block (conv_block.py:57-136 of the reference) as ONE kernel for the
+// data-gradient chain, mirroring sir_fused.hip: a workgroup owns whole images, so the three GroupNorm backward
+// reductions are workgroup-local, the two pointwise data-gradients run on MFMA from LDS tiles, and the depthwise
+// data-gradient and weight-gradient share one pass over the LDS-resident neighbours:
+//
+//   dy -> GN3' -> d_o --(x Wp)--> GN2'/act' -> dd --depthwise^T--> GN1'/act' -> d_e --(x We)--> dropout' -> + dy -> dx
+//
+// Written to memory: dx, d_o and d_e (operands of the two pointwise weight-gradient GEMMs, which sum over the whole
+// batch and stay separate launches) and per-image / per-workgroup fp32 partial sums of every per-channel parameter
+// gradient (GroupNorm gamma/beta, the three biases, the nine depthwise taps), folded by the caller's reduction pass.
+// Everything that feeds the data gradients is summed in a fixed order (per-wave slots), so dx, d_o, d_e and the
+// GroupNorm / bias partials are bit-reproducible; only the nine depthwise tap gradients (leaf values) are folded
+// across waves with LDS float atomics.
+#include "common.h"
+#include "ddpm_hip.h"
+#include "sir_tile.h"
+
+struct SirBwdArgs {
+    const bf16* dy;
+    const bf16* raw_e; const bf16* raw_d; const bf16* raw_o; const bf16* y_e;
+    const float* st1; const float* st2; const float* st3;
+    const float* g1; const float* b1; const float* g2; const float* b2; const float* g3;
+    const bf16* wpd;                 // [E][C]  data-gradient copy of the projection weight (rows = its input channels)
+    const bf16* wed;                 // [C][E]  data-gradient copy of the expansion weight
+    const float* wdf;                // [9][E]  depthwise taps, flipped
+    const unsigned char* m_in; const unsigned char* m_e; const unsigned char* m_d;
+    float mscale;
+    bf16* dx; bf16* d_o; bf16* d_e;
+    float* part1; float* part2; float* part3;      // [N][3][E], [N][3][E], [N][3][C]: d gamma, d beta, column sum of the raw gradient
+    float* dwpart;                                 // [workgroups][10][E]: nine tap gradients, then the depthwise bias gradient
+    int N, act;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_d(float z) {
+    if constexpr (ACT == ACT_GELU) { float c, g; gelu_parts(z, c, g); return c + z * 0.39894228040143268f * g; }
+    else if constexpr (ACT == ACT_SILU) { const float s = sigmoid_fast(z); return s * (1.0f + z * (1.0f - s)); }
+    else if constexpr (ACT == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    else return 1.f;
+}
+
+// Add this thread's per-channel values into the workgroup's [IPW][CS] column table: wave reduction over the lanes that
+// hold other rows of the same channels, then one LDS atomic per channel and wave.
+template <int CH, int M, int CS>
+__device__ __forceinline__ void col_add(const float (&v)[8], int img, int vec, int lane, float* s_tab) {
+    using T = Ew<CH, M>;
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r[j] = v[j];
+#pragma unroll
+        for (int o = T::VPR; o < 64; o <<= 1) r[j] += __shfl_xor(r[j], o, 64);
+    }
+    if (lane < T::VPR) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&s_tab[img * CS + vec * 8 + j], r[j]);
+    }
+}
+
+// Deterministic column sums: a thread owns NV consecutive rows, so all rows of a wave belong to one image; the wave
+// reduces over its rows with shuffles and stores one value per channel into its own slot [wave][CS]; the finalising
+// thread of (image, channel) adds the slots of the image's waves in a fixed order.
+template <int CH, int M, int CS>
+__device__ __forceinline__ void col_store(const float (&v)[8], int wave, int vec, int lane, float* s_slot) {
+    using T = Ew<CH, M>;
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r[j] = v[j];
+#pragma unroll
+        for (int o = T::VPR; o < 64; o <<= 1) r[j] += __shfl_xor(r[j], o, 64);
+    }
+    if (lane < T::VPR) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_slot[wave * CS + vec * 8 + j] = r[j];
+    }
+}
+
+template <int IPW, int CS>
+__device__ __forceinline__ float col_total(const float* s_slot, int img, int c) {
+    constexpr int NWV = SIR_THREADS / 64, WPI = NWV / IPW;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPI; ++w) t += s_slot[(img * WPI + w) * CS + c];
+    return t;
+}
+
+// GroupNorm (+activation, +dropout) backward over the vectors a thread holds (rows r0*NV .. r0*NV+NV-1).
+// g[][]: in = gradient w.r.t. the (masked, activated) output of this norm, out = gradient w.r.t. the raw convolution
+// output.  s_slot: [3][waves][CS] scratch; on return table 2 holds the per-wave column sums of the result (the bias
+// gradient of the producing convolution), to be read with col_total after the caller's next barrier.
+template <int CH, int M, int HW, int IPW, int CS, int ACT>
+__device__ __forceinline__ void norm_bwd(const bf16x8 (&raw)[Ew<CH, M>::NV], float (&g)[Ew<CH, M>::NV][8], const unsigned (&mk)[Ew<CH, M>::NV],
+                                         bool use_mask, float mscale, const float* gamma, const float* beta, const float* s_mr,
+                                         float* s_slot, float* s_grp, float* part, long long n0, int N, int tid) {
+    using T = Ew<CH, M>;
+    constexpr int NWV = SIR_THREADS / 64;
+    static_assert(NWV % IPW == 0 && (M / NWV) <= HW, "a wave must not straddle images");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int vec = tid % T::VPR, r0 = tid / T::VPR;
+    const int img = IPW > 1 ? (r0 * T::NV) / HW : 0;          // the same for every row of this thread (and of its wave)
+    float ga[8], be[8], mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int grp = (vec * 8 + j) / T::CPG;
+        ga[j] = gamma[vec * 8 + j]; be[j] = ACT != ACT_NONE ? beta[vec * 8 + j] : 0.f;
+        mean[j] = s_mr[(img * SIR_G + grp) * 2]; rstd[j] = s_mr[(img * SIR_G + grp) * 2 + 1];
+    }
+    float a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < T::NV; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)raw[k][j] - mean[j]) * rstd[j];
+            float gg = g[k][j];
+            if constexpr (ACT != ACT_NONE) gg *= act_d<ACT>(xh * ga[j] + be[j]);
+            if (use_mask) gg = (mk[k] >> j) & 1 ? gg * mscale : 0.f;
+            g[k][j] = gg;
+            a1[j] += gg; a2[j] += gg * xh;
+        }
+    }
+    col_store<CH, M, CS>(a1, wave, vec, lane, s_slot);
+    col_store<CH, M, CS>(a2, wave, vec, lane, s_slot + NWV * CS);
+    __syncthreads();
+    // per-channel totals -> parameter-gradient partials; gamma-weighted group sums for the second pass
+    for (int t = tid; t < IPW * CH; t += SIR_THREADS) {
+        const int im_ = t / CH, c = t % CH;
+        const float A1 = col_total<IPW, CS>(s_slot, im_, c), A2 = col_total<IPW, CS>(s_slot + NWV * CS, im_, c);
+        if (n0 + im_ < N) {
+            part[((n0 + im_) * 3 + 0) * CH + c] = A2;
+            part[((n0 + im_) * 3 + 1) * CH + c] = A1;
+        }
+        const float gm = gamma[c];
+        float u = A1 * gm, v = A2 * gm;
+#pragma unroll
+        for (int o = 1; o < T::CPG; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+        if ((c % T::CPG) == 0) {
+            const float inv = 1.0f / (float)(T::CPG * HW);
+            s_grp[(im_ * SIR_G + c / T::CPG) * 2] = u * inv;
+            s_grp[(im_ * SIR_G + c / T::CPG) * 2 + 1] = v * inv;
+        }
+    }
+    __syncthreads();
+    float db[8], S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int grp = (vec * 8 + j) / T::CPG;
+        db[j] = 0.f;
+        S1[j] = s_grp[(img * SIR_G + grp) * 2]; S2[j] = s_grp[(img * SIR_G + grp) * 2 + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < T::NV; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)raw[k][j] - mean[j]) * rstd[j];
+            const float d = rstd[j] * (ga[j] * g[k][j] - (S1[j] + xh * S2[j]));
+            g[k][j] = d;
+            db[j] += d;
+        }
+    }
+    col_store<CH, M, CS>(db, wave, vec, lane, s_slot + 2 * NWV * CS);
+}
+
+// After a barrier that follows norm_bwd: row 2 of the partial table (column sums of the raw gradient).
+template <int CH, int IPW, int CS>
+__device__ __forceinline__ void col2_flush(const float* s_slot, float* part, long long n0, int N, int tid) {
+    constexpr int NWV = SIR_THREADS / 64;
+    for (int t = tid; t < IPW * CH; t += SIR_THREADS) {
+        const int img = t / CH, c = t % CH;
+        const float v = col_total<IPW, CS>(s_slot + 2 * NWV * CS, img, c);
+        if (n0 + img < N) part[((n0 + img) * 3 + 2) * CH + c] = v;
+    }
+}
+
+template <int C, int W, int ACT>
+__device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
+    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
+    constexpr int NWV = SIR_THREADS / 64, MT = M / 32;
+    using E1 = Ew<E, M>;
+    using E3 = Ew<C, M>;
+    char* s_x = smem;                              // [M][XS]  d_o, later the expansion data-gradient
+    char* s_e = s_x + M * XS;                      // [M][ES]  projection data-gradient -> dd -> d_e
+    float* s_col = (float*)(s_e + M * ES);         // [3][waves][E] per-wave column sums
+    float* s_grp = s_col + 3 * NWV * E;            // [IPW][16][2]
+    float* s_mr = s_grp + IPW * 2 * SIR_G;         // [3][IPW][16][2]  mean, rstd of the three norms
+    float* s_p = s_mr + 3 * IPW * 2 * SIR_G;       // per-channel parameters
+    constexpr int P_G1 = 0, P_B1 = E, P_G2 = 2 * E, P_B2 = 3 * E, P_WD = 4 * E, P_G3 = 13 * E;
+    float* s_dw = s_p + 13 * E + C;                // [10][E] depthwise tap gradients (rows 0-8) and bias gradient (row 9) of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long n0 = (long long)blockIdx.x * IPW;
+    const long long row0 = n0 * HW;
+    const int rows_valid = (int)min((long long)M, (a.N - n0) * HW);
+    const bool use_mask = a.m_e != nullptr;
+
+    // ---- one round trip for everything small; zero the reduction tables
+    for (int i = tid; i < 9 * E; i += SIR_THREADS) { s_dw[i] = 0.f; s_p[P_WD + i] = a.wdf[i]; }
+    for (int i = tid; i < E; i += SIR_THREADS) s_dw[9 * E + i] = 0.f;
+    for (int i = tid; i < E; i += SIR_THREADS) {
+        s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i]; s_p[P_G2 + i] = a.g2[i]; s_p[P_B2 + i] = a.b2[i];
+    }
+    for (int i = tid; i < C; i += SIR_THREADS) s_p[P_G3 + i] = a.g3[i];
+    for (int i = tid; i < 3 * IPW * 2 * SIR_G; i += SIR_THREADS) {
+        const int which = i / (IPW * 2 * SIR_G), rem = i % (IPW * 2 * SIR_G);
+        const float* st = which == 0 ? a.st1 : which == 1 ? a.st2 : a.st3;
+        s_mr[i] = (n0 + rem / (2 * SIR_G) < a.N) ? st[n0 * 2 * SIR_G + rem] : 0.f;
+    }
+    const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
+    const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
+    bf16x8 dyv[E3::NV], rawo[E3::NV];
+    unsigned mk_in[E3::NV], mk_none3[E3::NV];
+#pragma unroll
+    for (int k = 0; k < E3::NV; ++k) {
+        const int row = r3 * E3::NV + k;
+        const long long e = (row0 + row) * C + v3 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dyv[k][j] = (bf16)0.f; rawo[k][j] = (bf16)0.f; }
+        mk_in[k] = 0xFFu; mk_none3[k] = 0xFFu;
+        if (row < rows_valid) {
+            dyv[k] = *(const bf16x8*)(a.dy + e);
+            rawo[k] = *(const bf16x8*)(a.raw_o + e);
+            if (a.m_in) mk_in[k] = a.m_in[e >> 3];
+        }
+    }
+    bf16x8 rawd[E1::NV];
+    unsigned mk_e[E1::NV], mk_d[E1::NV];
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) {
+        const int row = r1 * E1::NV + k;
+        const long long e = (row0 + row) * E + v1 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rawd[k][j] = (bf16)0.f;
+        mk_e[k] = mk_d[k] = 0xFFu;
+        if (row < rows_valid) {
+            rawd[k] = *(const bf16x8*)(a.raw_d + e);
+            if (use_mask) { mk_e[k] = a.m_e[e >> 3]; mk_d[k] = a.m_d[e >> 3]; }
+        }
+    }
+    bf16x8 bfrag1[GemmK<C>::KCH];
+    if (wave < MT * (E / 32)) gemm_prefetch<C>(bfrag1, a.wpd + (long long)((wave / MT) * 32 + (lane & 31)) * C, lane);
+    __syncthreads();
+
+    // ---- last GroupNorm backward (no activation, no dropout): dy -> d_o
+    {
+        float g[E3::NV][8];
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[k][j] = (float)dyv[k][j];
+        norm_bwd<C, M, HW, IPW, E, ACT_NONE>(rawo, g, mk_none3, false, 1.f, s_p + P_G3, s_p + P_G3, s_mr + 2 * IPW * 2 * SIR_G, s_col, s_grp,
+                                            a.part3, n0, a.N, tid);
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const int row = r3 * E3::NV + k;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)g[k][j];
+            *(bf16x8*)(s_x + row * XS + v3 * 16) = o;
+            if (row < rows_valid) *(bf16x8*)(a.d_o + (row0 + row) * C + v3 * 8) = o;
+        }
+    }
+    __syncthreads();
+    col2_flush<C, IPW, E>(s_col, a.part3, n0, a.N, tid);
+
+    // ---- projection data-gradient: [M][C] x [E][C]^T -> LDS tile (bf16)
+    {
+        constexpr int TT = MT * (E / 32);
+#pragma unroll 1
+        for (int t = wave; t < TT; t += NWV) {
+            const int mt = t % MT, nt = t / MT;
+            const int col = nt * 32 + (lane & 31);
+            if (t != wave) gemm_prefetch<C>(bfrag1, a.wpd + (long long)col * C, lane);
+            const f32x16 acc = gemm_tile<C, XS>(s_x, mt * 32, a.wpd + (long long)col * C, lane, bfrag1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_e + row * ES + col * 2) = (bf16)acc[r];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- second GroupNorm + activation + dropout backward -> dd (kept in registers as fp32 and in the LDS tile as bf16)
+    float g[E1::NV][8];
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) {
+        const bf16x8 t = *(const bf16x8*)(s_e + (r1 * E1::NV + k) * ES + v1 * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[k][j] = (float)t[j];
+    }
+    norm_bwd<E, M, HW, IPW, E, ACT>(rawd, g, mk_d, use_mask, a.mscale, s_p + P_G2, s_p + P_B2, s_mr + IPW * 2 * SIR_G, s_col, s_grp, a.part2,
+                                   n0, a.N, tid);
+    // the forward activation feeding the depthwise conv and the raw expansion output are needed next: request them now
+    bf16x8 yev[E1::NV], rawe[E1::NV];
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) {
+        const int row = r1 * E1::NV + k;
+        const long long e = (row0 + row) * E + v1 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { yev[k][j] = (bf16)0.f; rawe[k][j] = (bf16)0.f; }
+        if (row < rows_valid) { yev[k] = *(const bf16x8*)(a.y_e + e); rawe[k] = *(const bf16x8*)(a.raw_e + e); }
+    }
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)g[k][j];
+        *(bf16x8*)(s_e + (r1 * E1::NV + k) * ES + v1 * 16) = o;
+    }
+    __syncthreads();
+    // table 2 of this norm = depthwise bias gradient: all waves (= all images of the workgroup) folded into row 9
+    for (int c = tid; c < E; c += SIR_THREADS) s_dw[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
+
+    // ---- depthwise: data-gradient (flipped taps) and weight-gradient share the neighbour reads of dd
+    {
+        float acc[E1::NV][8];
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // neighbour q - off(tap) of the forward stencil = q + off(8 - tap); wdf holds the taps flipped, so tap index
+            // t2 = 8 - tap of wdf multiplies dd[q + off(t2)] in the data-gradient, and the same neighbour times the
+            // forward activation at q is the gradient of forward tap `tap`.
+            const int t2 = 8 - tap;
+            const int dy = t2 / 3 - 1, dx = t2 % 3 - 1;
+            float w[8], wg[8];
+            const f32x4 w0 = *(const f32x4*)(s_p + P_WD + t2 * E + v1 * 8), w1 = *(const f32x4*)(s_p + P_WD + t2 * E + v1 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = w0[j]; w[4 + j] = w1[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wg[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < E1::NV; ++k) {
+                const int row = r1 * E1::NV + k;
+                const int p = row % HW, py = p / W, px = p % W;
+                const int ny = py + dy, nx = px + dx;
+                if (ny >= 0 && ny < W && nx >= 0 && nx < W) {
+                    const bf16x8 nv = *(const bf16x8*)(s_e + (row + dy * W + dx) * ES + v1 * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (float)nv[j];
+                        acc[k][j] += f * w[j];
+                        wg[j] += f * (float)yev[k][j];
+                    }
+                }
+            }
+            col_add<E, M, E>(wg, 0, v1, lane, s_dw + tap * E);
+        }
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[k][j] = (float)(bf16)acc[k][j];     // the unfused path stores this tensor as bf16
+    }
+
+    // ---- first GroupNorm + activation + dropout backward -> d_e
+    bf16x8 bfrag2[GemmK<E>::KCH];
+    if (wave < MT * (C / 32)) gemm_prefetch<E>(bfrag2, a.wed + (long long)((wave / MT) * 32 + (lane & 31)) * E, lane);
+    norm_bwd<E, M, HW, IPW, E, ACT>(rawe, g, mk_e, use_mask, a.mscale, s_p + P_G1, s_p + P_B1, s_mr, s_col + 0, s_grp, a.part1, n0, a.N, tid);
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) {
+        const int row = r1 * E1::NV + k;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)g[k][j];
+        *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
+        if (row < rows_valid) *(bf16x8*)(a.d_e + (row0 + row) * E + v1 * 8) = o;
+    }
+    __syncthreads();
+    col2_flush<E, IPW, E>(s_col, a.part1, n0, a.N, tid);
+    // depthwise tap and bias gradients of this workgroup (complete since the barrier above)
+    for (int i = tid; i < 10 * E; i += SIR_THREADS) a.dwpart[(long long)blockIdx.x * 10 * E + i] = s_dw[i];
+
+    // ---- expansion data-gradient: [M][E] x [C][E]^T -> LDS (bf16)
+    {
+        constexpr int TT = MT * (C / 32);
+#pragma unroll 1
+        for (int t = wave; t < TT; t += NWV) {
+            const int mt = t % MT, nt = t / MT;
+            const int col = nt * 32 + (lane & 31);
+            if (t != wave) gemm_prefetch<E>(bfrag2, a.wed + (long long)col * E, lane);
+            const f32x16 acc = gemm_tile<E, ES>(s_e, mt * 32, a.wed + (long long)col * E, lane, bfrag2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_x + row * XS + col * 2) = (bf16)acc[r];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- dropout of the block input and the residual branch: dx = dy + mask * scale * (expansion data-gradient)
+#pragma unroll
+    for (int k = 0; k < E3::NV; ++k) {
+        const int row = r3 * E3::NV + k;
+        if (row >= rows_valid) continue;
+        const bf16x8 t = *(const bf16x8*)(s_x + row * XS + v3 * 16);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = (float)t[j];
+            if (a.m_in) d = (mk_in[k] >> j) & 1 ? (float)(bf16)(d * a.mscale) : 0.f;
+            o[j] = (bf16)(d + (float)dyv[k][j]);
+        }
+        *(bf16x8*)(a.dx + (row0 + row) * C + v3 * 8) = o;
+    }
+}
+
+template <int C, int W>
+__global__ __launch_bounds__(SIR_THREADS) void sir_bwd_kernel(const SirBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    switch (a.act) {
+        case ACT_GELU: sir_bwd_body<C, W, ACT_GELU>(a, smem); break;
+        case ACT_SILU: sir_bwd_body<C, W, ACT_SILU>(a, smem); break;
+        default: sir_bwd_body<C, W, ACT_RELU>(a, smem); break;
+    }
+}
+
+template <int C, int W>
+static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
+    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) +
+                        (3 * (SIR_THREADS / 64) * E + IPW * 2 * SIR_G + 3 * IPW * 2 * SIR_G + 13 * E + C + 10 * E) * 4;
+    static_assert(lds <= 160 * 1024, "tiles do not fit LDS");
+    auto k = sir_bwd_kernel<C, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            ddpm_set_error("sir_backward: cannot reserve %d bytes of LDS", lds);
+            return DDPM_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3((a.N + IPW - 1) / IPW), dim3(SIR_THREADS), lds, stream, a);
+    return ddpm_check_launch("sir_backward");
+}
+
+extern "C" int ddpm_sir_workgroups(int HW, int N) {
+    const int ipw = HW >= 32 ? 1 : 32 / HW;
+    return (N + ipw - 1) / ipw;
+}
+
+extern "C" int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(d && d->dy && d->raw_e && d->raw_d && d->raw_o && d->y_e && d->st1 && d->st2 && d->st3 && d->g1 && d->b1 && d->g2 &&
+                     d->b2 && d->g3 && d->wpd && d->wed && d->wdf && d->dx && d->d_o && d->d_e && d->part1 && d->part2 && d->part3 &&
+                     d->dwpart, "sir_backward: null pointer");
+    DDPM_REQUIRE(d->N > 0, "sir_backward: N must be positive");
+    DDPM_REQUIRE(ddpm_sir_supported(d->C, d->H, d->W, d->E, d->groups, d->act),
+                 "sir_backward: unsupported shape C=%d %dx%d E=%d groups=%d act=%d (use the unfused kernels)", d->C, d->H, d->W, d->E,
+                 d->groups, d->act);
+    DDPM_REQUIRE((d->m_in != nullptr) == (d->m_e != nullptr) && (d->m_e != nullptr) == (d->m_d != nullptr),
+                 "sir_backward: give all three dropout masks or none");
+    SirBwdArgs a;
+    a.dy = (const bf16*)d->dy; a.raw_e = (const bf16*)d->raw_e; a.raw_d = (const bf16*)d->raw_d; a.raw_o = (const bf16*)d->raw_o;
+    a.y_e = (const bf16*)d->y_e; a.st1 = d->st1; a.st2 = d->st2; a.st3 = d->st3;
+    a.g1 = d->g1; a.b1 = d->b1; a.g2 = d->g2; a.b2 = d->b2; a.g3 = d->g3;
+    a.wpd = (const bf16*)d->wpd; a.wed = (const bf16*)d->wed; a.wdf = d->wdf;
+    a.m_in = d->m_in; a.m_e = d->m_e; a.m_d = d->m_d; a.mscale = d->mask_scale;
+    a.dx = (bf16*)d->dx; a.d_o = (bf16*)d->d_o; a.d_e = (bf16*)d->d_e;
+    a.part1 = d->part1; a.part2 = d->part2; a.part3 = d->part3; a.dwpart = d->dwpart;
+    a.N = d->N; a.act = d->act;
+    if (d->C == 32 && d->W == 16) return sir_bwd_launch<32, 16>(a, stream);
+    if (d->C == 64 && d->W == 8) return sir_bwd_launch<64, 8>(a, stream);
+    if (d->C == 128 && d->W == 4) return sir_bwd_launch<128, 4>(a, stream);
+    if (d->C == 256 && d->W == 2) return sir_bwd_launch<256, 2>(a, stream);
+    if (d->C == 128 && d->W == 8) return sir_bwd_launch<128, 8>(a, stream);
+    return sir_bwd_launch<256, 4>(a, stream);
+}

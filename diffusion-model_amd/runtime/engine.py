@@ -317,10 +317,23 @@ class UNetEngine:
                                         record=tape is not None)
                 out = Var(y)
                 if tape is not None:
-                    ev, dv = Var(sv["y_e"]), Var(sv["y_d"])
-                    tape.append(conv_bwd(ne, xin, None, None, m_in, sv["raw_e"], ev, sv["st1"], g1, sp.groups, sp.act, None, m_e))
-                    tape.append(dw_bwd(pre, ev, sv["raw_d"], dv, sv["st2"], m_d))
-                    tape.append(conv_bwd(npj, dv, None, None, None, sv["raw_o"], out, sv["st3"], g3, sp.groups, 0, xin, None))
+                    def bwd():
+                        # data-gradient chain in one launch; the two pointwise weight gradients sum over the batch
+                        # and stay separate GEMM launches
+                        p1, p2, p3 = gn_partials(ech, g1, ne), gn_partials(ech, g2, None), gn_partials(cc, g3, npj)
+                        nwg = ops.sir_workgroups(hh * ww, n)
+                        dwbuf, off = part_alloc(nwg * 10 * ech)
+                        part_entries.append((off, G.offset(nd + ".weight"), nwg, 10 * ech, 9 * ech))
+                        part_entries.append((off + 9 * ech, G.offset(nd + ".bias"), nwg, 10 * ech, ech))
+                        dx, d_o, d_e = ops.sir_backward(out.g, sv, P[g1 + ".weight"], P[g1 + ".bias"], P[g2 + ".weight"], P[g2 + ".bias"],
+                                                        P[g3 + ".weight"], wc.dgrad[npj], wc.dgrad[ne], wc.dw_flip[nd], sp.groups, sp.act,
+                                                        p1, p2, p3, dwbuf, masks=(m_in, m_e, m_d), mask_scale=mscale)
+                        out.g = None
+                        ops.conv_wgrad(K11, sv["y_d"], d_o, cc, G[npj + ".weight"])
+                        ops.conv_wgrad(K11, xin.v, d_e, ech, G[ne + ".weight"], in_mask=m_in, in_scale=mscale)
+                        assert xin.g is None
+                        xin.g = dx
+                    tape.append(bwd)
                 return out
             e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
             d = dw_unit(pre, e, m_d)

@@ -46,6 +46,12 @@ class SirDesc(C.Structure):
         (k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act", "pad")]
 
 
+class SirBwdDesc(C.Structure):
+    _fields_ = [(k, _vp) for k in ("dy", "raw_e", "raw_d", "raw_o", "y_e", "st1", "st2", "st3", "g1", "b1", "g2", "b2", "g3", "wpd", "wed",
+                                   "wdf", "m_in", "m_e", "m_d", "dx", "d_o", "d_e", "part1", "part2", "part3", "dwpart")] + [
+        ("mask_scale", _f)] + [(k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act")]
+
+
 class ReduceEntry(C.Structure):
     _fields_ = [("src_off", _i64), ("dst_off", _i64), ("rows", C.c_int32), ("row_stride", C.c_int32), ("width", C.c_int32),
                 ("pad", C.c_int32)]
@@ -87,6 +93,8 @@ _PROTOS = {
     "ddpm_remap_chunk_elems": ([], _i),
     "ddpm_sir_supported": ([_i, _i, _i, _i, _i, _i], _i),
     "ddpm_sir_forward": ([_vp, _vp], _i),
+    "ddpm_sir_workgroups": ([_i, _i], _i),
+    "ddpm_sir_backward": ([_vp, _vp], _i),
     "ddpm_adam_step": ([_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _vp, _vp], _i),
     "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
     "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),

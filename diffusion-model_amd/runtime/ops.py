@@ -168,6 +168,38 @@ def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: T
     return y, saved
 
 
+def sir_workgroups(hw: int, n: int) -> int:
+    return hip.lib().ddpm_sir_workgroups(hw, n)
+
+
+def sir_backward(dy: Tensor, saved: dict, g1: Tensor, b1: Tensor, g2: Tensor, b2: Tensor, g3: Tensor, wpd: Tensor, wed: Tensor,
+                 wdf: Tensor, groups: int, act: int, part1: Tensor, part2: Tensor, part3: Tensor, dwpart: Tensor, *,
+                 masks=(None, None, None), mask_scale: float = 1.0):
+    """Data-gradient chain of one fused block.  saved: what sir_forward(record=True) returned.  wpd: bf16 [1][E][C],
+    wed: bf16 [1][C][E] (data-gradient weight copies), wdf: fp32 [9][E] flipped taps.  Returns (dx, d_o, d_e)."""
+    n, h, w, c = dy.shape
+    e = wdf.shape[1]
+    assert dy.dtype == BF16 and dy.is_contiguous() and wpd.shape[-2:] == (e, c) and wed.shape[-2:] == (c, e)
+    assert part1.numel() == n * 3 * e and part2.numel() == n * 3 * e and part3.numel() == n * 3 * c
+    assert dwpart.numel() == sir_workgroups(h * w, n) * 10 * e
+    dx = torch.empty_like(dy)
+    d_o = torch.empty_like(dy)
+    d_e = torch.empty(n, h, w, e, device=dy.device, dtype=BF16)
+    d = hip.SirBwdDesc(dy=hip.ptr(dy), raw_e=hip.ptr(saved["raw_e"]), raw_d=hip.ptr(saved["raw_d"]), raw_o=hip.ptr(saved["raw_o"]),
+                       y_e=hip.ptr(saved["y_e"]), st1=hip.ptr(saved["st1"]), st2=hip.ptr(saved["st2"]), st3=hip.ptr(saved["st3"]),
+                       g1=hip.ptr(g1), b1=hip.ptr(b1), g2=hip.ptr(g2), b2=hip.ptr(b2), g3=hip.ptr(g3), wpd=hip.ptr(wpd), wed=hip.ptr(wed),
+                       wdf=hip.ptr(wdf), m_in=hip.ptr(masks[0]), m_e=hip.ptr(masks[1]), m_d=hip.ptr(masks[2]), dx=hip.ptr(dx),
+                       d_o=hip.ptr(d_o), d_e=hip.ptr(d_e), part1=hip.ptr(part1), part2=hip.ptr(part2), part3=hip.ptr(part3),
+                       dwpart=hip.ptr(dwpart), mask_scale=mask_scale, N=n, C=c, H=h, W=w, E=e, groups=groups, act=act)
+
+    def cost():
+        nb = _nb(dy, dx, d_o, d_e, wpd, wed, saved["raw_e"], saved["raw_d"], saved["raw_o"], saved["y_e"]) + sum(_nb(m) for m in masks)
+        return nb, 2.0 * n * h * w * (2 * c * e + 18 * e), f"{h}x{w} C{c} E{e}"
+
+    _launch("sir_bwd_kernel", cost, lambda: hip.call("ddpm_sir_backward", C.byref(d), hip.stream()))
+    return dx, d_o, d_e
+
+
 def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
     """x: NHWC bf16; w9c: fp32 [9][C] tap-major."""
     n, h, w, c = x.shape

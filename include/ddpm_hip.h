@@ -224,6 +224,29 @@ typedef struct ddpm_sir_desc {
 int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act);
 int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream);
 
+/* Data-gradient chain of the same block (backward of ddpm_sir_forward) in one launch.  dy: gradient w.r.t. the block
+ * output.  raw_e/raw_d/raw_o/y_e/st1-3: what ddpm_sir_forward saved.  wpd: bf16 [E][C], wed: bf16 [C][E] (the
+ * data-gradient weight-copy layout of ddpm_conv_forward's DGRAD kinds for the projection / expansion), wdf: fp32 [9][E]
+ * depthwise taps flipped.  Outputs: dx (gradient w.r.t. the block input, residual branch included), d_o [N][H][W][C] and
+ * d_e [N][H][W][E] (gradients w.r.t. the raw projection / expansion outputs = the dY operands of ddpm_conv_wgrad), and
+ * fp32 partial sums for ddpm_reduce_rows: part1/part2 [N][3][E], part3 [N][3][C] (rows: d gamma, d beta, column sum of the
+ * raw gradient = bias gradient of the producing convolution; row 2 of part2 is not written), dwpart
+ * [ddpm_sir_workgroups(H*W, N)][10][E] (nine depthwise tap gradients, then the depthwise bias gradient). */
+typedef struct ddpm_sir_bwd_desc {
+    const void* dy;
+    const void* raw_e; const void* raw_d; const void* raw_o; const void* y_e;
+    const float* st1; const float* st2; const float* st3;
+    const float* g1; const float* b1; const float* g2; const float* b2; const float* g3;
+    const void* wpd; const void* wed; const float* wdf;
+    const uint8_t* m_in; const uint8_t* m_e; const uint8_t* m_d;
+    void* dx; void* d_o; void* d_e;
+    float* part1; float* part2; float* part3; float* dwpart;
+    float mask_scale;
+    int32_t N, C, H, W, E, groups, act;
+} ddpm_sir_bwd_desc;
+int ddpm_sir_workgroups(int HW, int N);
+int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,3 +82,48 @@ def test_unsupported_shapes_are_refused(dev):
     assert not ops.sir_supported(32, 32, 32, 64, 16, hip.ACT["gelu"])       # too large for one workgroup's LDS
     assert not ops.sir_supported(64, 8, 8, 256, 16, hip.ACT["gelu"])        # expansion factor other than 2
     assert not ops.sir_supported(64, 8, 8, 128, 8, hip.ACT["gelu"])         # other group count
+
+
+@pytest.mark.parametrize("n,c,w", SHAPES)
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_block_backward_vs_autograd(dev, n, c, w, train):
+    """One-launch data-gradient chain (+ per-channel parameter-gradient partials) against torch autograd through the
+    restated block.  Data gradients pass 3-6 bf16 rounding points: 3e-2 of scale; parameter gradients (fp32 sums) 2e-2."""
+    e = 2 * c
+    act = "gelu" if train else "silu"
+    x = r16(hash_normal((n, c, w, w), 31) * 1.2).requires_grad_(True)
+    P = {k: v.requires_grad_(True) for k, v in make_params(c, e, 5 * c + w).items()}
+    if train:
+        keeps, scale = (hash_uniform((n, w, w, c), 41) < 0.9, hash_uniform((n, w, w, e), 42) < 0.9, hash_uniform((n, w, w, e), 43) < 0.9), 1 / 0.9
+    else:
+        keeps, scale = (None, None, None), 1.0
+    ref = reference(x, P, act, keeps, scale)
+    gy = r16(hash_normal((n, c, w, w), 33))
+    names = ["we", "be", "g1", "b1", "wd", "bd", "g2", "b2", "wp", "bp", "g3", "b3"]
+    grads = torch.autograd.grad(ref["y"], [x, ref["raw_o"], ref["raw_e"]] + [P[k] for k in names], gy)
+    gx, g_o, g_e = grads[:3]
+    gp = dict(zip(names, grads[3:]))
+
+    Pd = {k: v.detach() for k, v in P.items()}
+    y, sv = run(dev, x.detach(), Pd, act, keeps, scale, record=True)
+    d = lambda t: t.detach().to(dev)                                             # noqa: E731
+    wpd = pack.pack_dgrad(hip.CONV_1X1, Pd["wp"]).to(dev)
+    wed = pack.pack_dgrad(hip.CONV_1X1, Pd["we"]).to(dev)
+    wdf = Pd["wd"].reshape(-1, 9).flip(1).t().contiguous().to(dev)
+    nwg = ops.sir_workgroups(w * w, n)
+    nan = float("nan")
+    p1, p2, p3 = (torch.full((n, 3, ch), nan, device=dev) for ch in (e, e, c))
+    dwp = torch.full((nwg, 10, e), nan, device=dev)
+    masks = tuple(None if k is None else bits(k).to(dev) for k in keeps)
+    dx, d_o, d_e = ops.sir_backward(nhwc(gy, dev), sv, d(P["g1"]), d(P["b1"]), d(P["g2"]), d(P["b2"]), d(P["g3"]), wpd, wed, wdf, 16,
+                                    hip.ACT[act], p1, p2, p3, dwp, masks=masks, mask_scale=scale)
+    assert_rel(nchw(d_o), g_o, 1.5e-2)
+    assert_rel(nchw(d_e), g_e, 3e-2)
+    assert_rel(nchw(dx), gx, 3e-2)
+    p1, p2, p3, dwp = p1.cpu(), p2.cpu(), p3.cpu(), dwp.cpu()
+    assert_rel(p3[:, 0].sum(0), gp["g3"], 2e-2); assert_rel(p3[:, 1].sum(0), gp["b3"], 2e-2); assert_rel(p3[:, 2].sum(0), gp["bp"], 2e-2)
+    assert_rel(p2[:, 0].sum(0), gp["g2"], 2e-2); assert_rel(p2[:, 1].sum(0), gp["b2"], 2e-2)
+    assert_rel(p1[:, 0].sum(0), gp["g1"], 2e-2); assert_rel(p1[:, 1].sum(0), gp["b1"], 2e-2); assert_rel(p1[:, 2].sum(0), gp["be"], 2e-2)
+    dw = dwp.sum(0)
+    assert_rel(dw[:9].t().reshape(e, 1, 3, 3), gp["wd"], 2e-2)
+    assert_rel(dw[9], gp["bd"], 2e-2)
