@@ -21,6 +21,8 @@ struct WgradArgs {
     const float* in_add; const unsigned char* in_mask; float in_mask_scale;
     const bf16* dy; int Cout, dy_cs;
     float* dw;
+    float* part;              // when set: per-split partial sums [gridDim.x][slices][Cout][Cin], plain stores, no atomics
+    long long dw_numel;
     int ntiles;
 };
 
@@ -192,11 +194,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         if (item >= nitems) continue;
         const int j = item / NCO, cosub = item - j * NCO;
         const int ci = c0 + (lane & 31);
-        float* base = a.dw + (long long)g.tap_slice[tap0 + j] * a.Cout * Cin;
+        const long long soff = (long long)g.tap_slice[tap0 + j] * a.Cout * Cin;
+        if (a.part) {
+            // two-stage reduction: the position splits of one weight tile would otherwise contend with atomics on the
+            // same few cache lines; each split stores its tile, one table-driven pass folds all layers later
+            float* base = a.part + (long long)blockIdx.x * a.dw_numel + soff;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + cosub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < a.Cout && ci < Cin) atomicAdd(base + (long long)co * Cin + ci, acc[i][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cosub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout && ci < Cin) base[(long long)co * Cin + ci] = acc[i][r];
+            }
+        } else {
+            float* base = a.dw + soff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cosub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout && ci < Cin) atomicAdd(base + (long long)co * Cin + ci, acc[i][r]);
+            }
         }
     }
 }
@@ -212,9 +226,15 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s
     return ddpm_check_launch("conv_wgrad");
 }
 
-extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    DDPM_REQUIRE(d && d->in0 && d->dy && d->dw, "wgrad: null pointer");
+struct WgradPlan {
+    WgradArgs a;
+    int nco, maxi;
+    dim3 grid;
+    size_t lds;
+};
+
+static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
+    DDPM_REQUIRE(d && d->in0 && d->dy && (d->dw || d->part), "wgrad: null pointer");
     DDPM_REQUIRE(d->kind == CONV_3X3_S1 || d->kind == CONV_3X3_S2 || d->kind == CONV_1X1 || d->kind == CONVT_2X2_S2,
                  "wgrad: kind %d is not a forward kind", d->kind);
     DDPM_REQUIRE(d->N > 0 && d->IH > 0 && d->IW > 0, "wgrad: bad dims");
@@ -222,27 +242,49 @@ extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) 
                  "wgrad: input channels must be multiples of 16 (32 when two sources are concatenated); got %d + %d", d->C0, d->C1);
     DDPM_REQUIRE(d->Cout > 0 && d->dy_cs >= d->Cout && d->dy_cs % 8 == 0, "wgrad: dy channel stride %d must be a multiple of 8 >= Cout %d",
                  d->dy_cs, d->Cout);
-    WgradArgs a;
+    WgradArgs& a = p.a;
     if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 128) != 0) { ddpm_set_error("wgrad: geometry"); return DDPM_EINVAL; }
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1;
     a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
-    a.dy = (const bf16*)d->dy; a.Cout = d->Cout; a.dy_cs = d->dy_cs; a.dw = d->dw;
+    a.dy = (const bf16*)d->dy; a.Cout = d->Cout; a.dy_cs = d->dy_cs; a.dw = d->dw; a.part = d->part;
     a.ntiles = a.g.tiles_n * a.g.tiles_h * a.g.tiles_w;
     const int Cin = d->C0 + d->C1;
+    const int slices = d->kind == CONV_1X1 ? 1 : d->kind == CONVT_2X2_S2 ? 4 : 9;
+    a.dw_numel = (long long)slices * d->Cout * Cin;
     const int co_sub = (d->Cout + 31) / 32;
     int nco = a.g.max_taps >= 9 ? 2 : 4;
     if (nco > co_sub) nco = co_sub;
     if (nco == 3) nco = 2;
     const int cob = (co_sub + nco - 1) / nco, nci = (Cin + CONV_CK - 1) / CONV_CK;
-    const int maxi = (a.g.max_taps * nco + 3) / 4;
+    p.nco = nco;
+    p.maxi = (a.g.max_taps * nco + 3) / 4;
     long long other = (long long)cob * nci * a.g.ncls;
     long long msplit = 512 / other;
     if (msplit < 1) msplit = 1;
     if (msplit > a.ntiles) msplit = a.ntiles;
     const int npix = a.g.NB * a.g.PH * a.g.PW;
-    const size_t lds = ((size_t)((npix + 3) & ~3) + 128 + 128) * 4 + (size_t)npix * CONV_RS + (size_t)128 * (nco * 64 + 16);
-    DDPM_REQUIRE(lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS", lds);
-    dim3 grid((unsigned)msplit, (unsigned)(cob * nci), (unsigned)a.g.ncls);
+    p.lds = ((size_t)((npix + 3) & ~3) + 128 + 128) * 4 + (size_t)npix * CONV_RS + (size_t)128 * (nco * 64 + 16);
+    DDPM_REQUIRE(p.lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS", p.lds);
+    p.grid = dim3((unsigned)msplit, (unsigned)(cob * nci), (unsigned)a.g.ncls);
+    return DDPM_OK;
+}
+
+extern "C" int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d) {
+    WgradPlan p;
+    ddpm_wgrad_desc tmp = *d;
+    if (!tmp.dw && !tmp.part) tmp.part = (float*)16;        // sizing query: output pointers are not needed yet
+    if (wgrad_plan(&tmp, p) != DDPM_OK) return -1;
+    return (int)p.grid.x;
+}
+
+extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WgradPlan p;
+    if (int rc = wgrad_plan(d, p)) return rc;
+    const WgradArgs& a = p.a;
+    const int nco = p.nco, maxi = p.maxi;
+    const dim3 grid = p.grid;
+    const size_t lds = p.lds;
 #define WG_CASE(NCOv, MAXIv) if (nco == NCOv && maxi == MAXIv) return launch_wgrad<NCOv, MAXIv>(a, grid, lds, stream);
     WG_CASE(1, 1) WG_CASE(2, 1) WG_CASE(4, 1)      /* 1-tap classes: 1x1, convT */
     WG_CASE(1, 3) WG_CASE(2, 5)                    /* 9 taps */

@@ -360,6 +360,14 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
         if (!sc && (long long)d->HW * (c / 8) <= 2048) sc = c;
     }
     if (!sc) sc = sc_min;
+    // a slab narrower than 64 bytes per pixel uses a fraction of every 128-byte line (and its sibling slabs fetch the
+    // same lines again): for big images prefer the widest slab on the two-pass path, whose second read is an L2 hit
+    {
+        int widest = 0;
+        for (int c = 64; c >= 8; c >>= 1)
+            if (!(d->C % c) && !(c % cpg) && c / cpg <= 32) { widest = c; break; }
+        if (sc < 32 && widest > sc) sc = widest;
+    }
     DDPM_REQUIRE(sc > 0, "%s: no slab width for C=%d, groups=%d", what, d->C, d->G);
     a.x = (const bf16*)d->x; a.gamma = d->gamma; a.beta = d->beta; a.res = (const bf16*)d->res; a.mask = d->mask;
     a.mask_scale = d->mask_scale; a.y = (bf16*)d->y; a.stats = d->stats; a.dy = (const bf16*)d->dy; a.part = d->part;

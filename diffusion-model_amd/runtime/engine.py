@@ -208,6 +208,21 @@ class UNetEngine:
                 part_entries.append((off + 2 * c, G.offset(conv_name + ".bias"), n, 3 * c, c))
             return buf
 
+        def wgrad(kind, x0t, dyt, cout, name, x1=None, in_add=None, in_mask=None):
+            """dense weight gradient: every position split stores its partial tile (no atomics on the few hot cache lines
+            of a small weight block); the end-of-backward reduction folds the rows into the gradient buffer"""
+            gw = G[name + ".weight"]
+            splits = ops.conv_wgrad_splits(kind, x0t, dyt, cout, x1=x1)
+            if splits <= 1:
+                ops.conv_wgrad(kind, x0t, dyt, cout, gw, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale)
+                return
+            numel = gw.numel()
+            buf, off = part_alloc(splits * numel)
+            ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale, part=buf)
+            dst = G.offset(name + ".weight")
+            for c0 in range(0, numel, 4096):
+                part_entries.append((off + c0, dst + c0, splits, numel, min(4096, numel - c0)))
+
         def next_mask():
             if not use_drop:
                 return None
@@ -253,8 +268,8 @@ class UNetEngine:
                 draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
                                            gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
                 out.g = None
-                ops.conv_wgrad(kind, x0.v, draw, cout, G[name + ".weight"], x1=None if x1 is None else x1.v,
-                               in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
+                wgrad(kind, x0.v, draw, cout, name, x1=None if x1 is None else x1.v,
+                      in_add=None if in_add is None else in_add.v, in_mask=in_mask)
                 if not x0.need_grad:
                     return                                  # network inputs (image, sinusoid) need no gradient
                 wd = wc.dgrad[name]
@@ -329,8 +344,8 @@ class UNetEngine:
                                                         P[g3 + ".weight"], wc.dgrad[npj], wc.dgrad[ne], wc.dw_flip[nd], sp.groups, sp.act,
                                                         p1, p2, p3, dwbuf, masks=(m_in, m_e, m_d), mask_scale=mscale)
                         out.g = None
-                        ops.conv_wgrad(K11, sv["y_d"], d_o, cc, G[npj + ".weight"])
-                        ops.conv_wgrad(K11, xin.v, d_e, ech, G[ne + ".weight"], in_mask=m_in, in_scale=mscale)
+                        wgrad(K11, sv["y_d"], d_o, cc, npj)
+                        wgrad(K11, xin.v, d_e, ech, ne, in_mask=m_in)
                         assert xin.g is None
                         xin.g = dx
                     tape.append(bwd)
@@ -352,7 +367,7 @@ class UNetEngine:
                 def bwd():
                     d = out.g.to(BF16).view(n, 1, 1, c)
                     ops.colsum(d, G[name + ".bias"], c)
-                    ops.conv_wgrad(K11, h0.v, d, c, G[name + ".weight"])
+                    wgrad(K11, h0.v, d, c, name)
                     h0.g = ops.conv_forward(K11, d, wc.dgrad[name], None, h0.v.shape[3])
                 tape.append(bwd)
             return out
@@ -402,7 +417,7 @@ class UNetEngine:
                 dy = out_holder.g.contiguous()
                 hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, 16, hip.stream())
                 ops.colsum(dz, G[name + ".bias"], c_img)
-                ops.conv_wgrad(K33, hfeat.v, dz, c_img, G[name + ".weight"])
+                wgrad(K33, hfeat.v, dz, c_img, name)
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
             tape.append(bwd_head)
 

@@ -67,7 +67,7 @@ class WgradDesc(C.Structure):
         ("kind", _i), ("N", _i), ("IH", _i), ("IW", _i),
         ("in0", _vp), ("in1", _vp), ("C0", _i), ("C1", _i),
         ("in_add", _vp), ("in_mask", _vp), ("in_mask_scale", _f),
-        ("dy", _vp), ("Cout", _i), ("dy_cs", _i), ("dw", _vp),
+        ("dy", _vp), ("Cout", _i), ("dy_cs", _i), ("dw", _vp), ("part", _vp),
     ]
 
 
@@ -91,6 +91,7 @@ _PROTOS = {
     "ddpm_reduce_rows": ([_vp, _vp, _vp, _i, _i, _vp], _i),
     "ddpm_remap": ([_vp, _vp, _i, _i, _vp], _i),
     "ddpm_remap_chunk_elems": ([], _i),
+    "ddpm_conv_wgrad_splits": ([_vp], _i),
     "ddpm_sir_supported": ([_i, _i, _i, _i, _i, _i], _i),
     "ddpm_sir_forward": ([_vp, _vp], _i),
     "ddpm_sir_workgroups": ([_i, _i], _i),

@@ -158,10 +158,14 @@ typedef struct ddpm_wgrad_desc {
     const float* in_add; const uint8_t* in_mask; float in_mask_scale;
     const void* dy;           /* NHWC bf16 gradient of the forward output, channel stride dy_cs */
     int Cout, dy_cs;
-    float* dw;                /* fp32 [slices][Cout][C0+C1], accumulated (+=) with atomics; caller zeroes */
+    float* dw;                /* fp32 [slices][Cout][C0+C1], accumulated (+=) with atomics; caller zeroes (unused when part is set) */
+    float* part;              /* optional fp32 [ddpm_conv_wgrad_splits(d)][slices][Cout][C0+C1]: when set, every position split
+                               * stores its partial sums there (each element written exactly once, no atomics) and the caller
+                               * folds the rows into dw with ddpm_reduce_rows */
 } ddpm_wgrad_desc;
 
 int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream);
+int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d);   /* rows of `part` for this problem (shape fields only are read); -1 on error */
 
 /* db[C] += column sums of an NHWC bf16 tensor [rows][cs] (first C channels); fp32 atomics. */
 int ddpm_colsum(const void* x, float* out, int64_t rows, int C, int cs, ddpm_stream_t stream);
