@@ -21,9 +21,10 @@ struct WgradArgs {
     const float* in_add; const unsigned char* in_mask; float in_mask_scale;
     const bf16* dy; int Cout, dy_cs;
     float* dw;
-    float* part;              // when set: per-split partial sums [gridDim.x][slices][Cout][Cin], plain stores, no atomics
+    float* part;              // when set: per-split partial sums [splits][slices][Cout][Cin], plain stores, no atomics
     long long dw_numel;
     int ntiles;
+    int gx, gy;               // grid of this problem: gx position splits x gy (output, input) channel blocks x ncls classes
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
@@ -40,17 +41,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
 #define WG_U 6
 
 template <int NCO, int MAXI>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz, const int gx, char* smem) {
     constexpr int T = 256, BM = 128;
     constexpr int DYS = NCO * 64 + 16;          // dY tile row stride (bytes)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cls = blockIdx.z;
+    const int cls = bz;
     const int tap0 = g.cls_tap_begin[cls], ntaps = g.cls_tap_begin[cls + 1] - tap0;
     const int Cin = a.C0 + a.C1;
     const int nci = (Cin + CONV_CK - 1) / CONV_CK;
-    const int cob = blockIdx.y / nci, cib = blockIdx.y - cob * nci;
+    const int cob = by / nci, cib = by - cob * nci;
     const int co0 = cob * 32 * NCO, c0 = cib * CONV_CK;
     const int parts = (Cin - c0 >= CONV_CK) ? 4 : (Cin - c0) / 8;
     const int PHW = g.PH * g.PW, npix = g.NB * PHW;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int kq = 8 * (grp >> 1) + q;                 // k row supplied by this lane (first read); +4 for the second
     const int colb = (16 * (grp & 1) + 4 * pp) * 2;    // byte offset of its 4 columns inside a 32-channel row
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = bx; tile < a.ntiles; tile += gx) {
         int t = tile;
         const int twi = t % g.tiles_w; t /= g.tiles_w;
         const int thi = t % g.tiles_h;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         if (a.part) {
             // two-stage reduction: the position splits of one weight tile would otherwise contend with atomics on the
             // same few cache lines; each split stores its tile, one table-driven pass folds all layers later
-            float* base = a.part + (long long)blockIdx.x * a.dw_numel + soff;
+            float* base = a.part + (long long)bx * a.dw_numel + soff;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + cosub * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -213,6 +213,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             }
         }
     }
+}
+
+template <int NCO, int MAXI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<NCO, MAXI>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, smem);
+}
+
+// Many independent weight-gradient problems in ONE launch: a weight gradient is a leaf of the backward pass, so all
+// of a network's can run together at its end, filling the machine instead of paying a latency-bound launch each.
+// tab: the problems of this kernel variant; first[p] = first flat workgroup of problem p (first[n] = total).
+template <int NCO, int MAXI>
+__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgradArgs* __restrict__ tab, const int* __restrict__ first, const int n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (first[mid] <= b) lo = mid; else hi = mid;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const WgradArgs& a = tab[lo];
+    const int local = b - first[lo];
+    const int gx = a.gx, gy = a.gy;
+    const int bx = local % gx, r = local / gx;
+    wgrad_body<NCO, MAXI>(a, bx, r % gy, r / gy, gx, smem);
 }
 
 template <int NCO, int MAXI>
@@ -266,6 +292,7 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     p.lds = ((size_t)((npix + 3) & ~3) + 128 + 128) * 4 + (size_t)npix * CONV_RS + (size_t)128 * (nco * 64 + 16);
     DDPM_REQUIRE(p.lds <= 160 * 1024, "wgrad: tile needs %zu B of LDS", p.lds);
     p.grid = dim3((unsigned)msplit, (unsigned)(cob * nci), (unsigned)a.g.ncls);
+    a.gx = (int)msplit; a.gy = cob * nci;
     return DDPM_OK;
 }
 
@@ -291,4 +318,101 @@ extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) 
 #undef WG_CASE
     ddpm_set_error("wgrad: no kernel for nco=%d items/wave=%d", nco, maxi);
     return DDPM_EINVAL;
+}
+
+// ---- grouped launch ---------------------------------------------------------------------------------------------
+// Blob layout (identical bytes on host and device): header, then per kernel variant the WgradArgs of its problems and
+// the prefix table of their workgroup counts.
+#define WG_VARIANTS 5
+static const int kVariantNco[WG_VARIANTS] = {1, 2, 4, 1, 2};
+static const int kVariantMaxi[WG_VARIANTS] = {1, 1, 1, 3, 5};
+
+struct WgradGroupHeader {
+    long long magic;
+    struct V { long long args_off, first_off, lds; int nprob, total_blocks; } v[WG_VARIANTS];
+};
+
+static inline long long align16(long long v) { return (v + 15) & ~15LL; }
+
+extern "C" int64_t ddpm_conv_wgrad_group_bytes(int n) {
+    if (n < 0) n = 0;
+    return align16(sizeof(WgradGroupHeader)) + WG_VARIANTS * 16 + align16((long long)n * sizeof(WgradArgs)) +
+           align16((long long)(n + WG_VARIANTS) * sizeof(int)) + 64;
+}
+
+extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, void* host_blob, int64_t bytes) {
+    DDPM_REQUIRE(descs && host_blob && n > 0, "wgrad group: bad arguments");
+    DDPM_REQUIRE(bytes >= ddpm_conv_wgrad_group_bytes(n), "wgrad group: blob of %lld bytes is too small for %d problems", (long long)bytes, n);
+    char* base = (char*)host_blob;
+    WgradGroupHeader* h = (WgradGroupHeader*)base;
+    h->magic = 0x5747524144LL;
+    static thread_local WgradPlan plans[1024];
+    DDPM_REQUIRE(n <= 1024, "wgrad group: at most 1024 problems per group");
+    int variant_of[1024];
+    for (int i = 0; i < n; ++i) {
+        if (int rc = wgrad_plan(&descs[i], plans[i])) return rc;
+        variant_of[i] = -1;
+        for (int v = 0; v < WG_VARIANTS; ++v)
+            if (plans[i].nco == kVariantNco[v] && plans[i].maxi == kVariantMaxi[v]) variant_of[i] = v;
+        DDPM_REQUIRE(variant_of[i] >= 0, "wgrad group: no kernel for nco=%d items/wave=%d", plans[i].nco, plans[i].maxi);
+    }
+    long long off = align16(sizeof(WgradGroupHeader));
+    for (int v = 0; v < WG_VARIANTS; ++v) {
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) cnt += variant_of[i] == v;
+        h->v[v].nprob = cnt;
+        h->v[v].args_off = off;
+        off = align16(off + (long long)cnt * sizeof(WgradArgs));
+        h->v[v].first_off = off;
+        off = align16(off + (long long)(cnt + 1) * sizeof(int));
+        WgradArgs* args = (WgradArgs*)(base + h->v[v].args_off);
+        int* first = (int*)(base + h->v[v].first_off);
+        int k = 0, blocks = 0;
+        long long lds = 0;
+        for (int i = 0; i < n; ++i) {
+            if (variant_of[i] != v) continue;
+            args[k] = plans[i].a;
+            first[k] = blocks;
+            blocks += (int)(plans[i].grid.x * plans[i].grid.y * plans[i].grid.z);
+            if ((long long)plans[i].lds > lds) lds = (long long)plans[i].lds;
+            ++k;
+        }
+        first[k] = blocks;
+        h->v[v].total_blocks = blocks;
+        h->v[v].lds = lds;
+    }
+    return DDPM_OK;
+}
+
+template <int NCO, int MAXI>
+static int launch_wgrad_group(const WgradGroupHeader::V& v, const char* dev, hipStream_t stream) {
+    auto k = conv_wgrad_group_kernel<NCO, MAXI>;
+    if (v.lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
+            return ddpm_check_launch("wgrad group: raise dynamic LDS limit");
+    }
+    hipLaunchKernelGGL(k, dim3(v.total_blocks), dim3(256), (size_t)v.lds, stream, (const WgradArgs*)(dev + v.args_off),
+                       (const int*)(dev + v.first_off), v.nprob);
+    return ddpm_check_launch("conv_wgrad_group");
+}
+
+extern "C" int ddpm_conv_wgrad_group_launch(const void* host_blob, const void* dev_blob, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(host_blob && dev_blob, "wgrad group: null blob");
+    const WgradGroupHeader* h = (const WgradGroupHeader*)host_blob;
+    DDPM_REQUIRE(h->magic == 0x5747524144LL, "wgrad group: blob was not produced by ddpm_conv_wgrad_group_plan");
+    const char* dev = (const char*)dev_blob;
+    for (int v = 0; v < WG_VARIANTS; ++v) {
+        if (h->v[v].nprob == 0) continue;
+        int rc = DDPM_OK;
+        switch (v) {
+            case 0: rc = launch_wgrad_group<1, 1>(h->v[v], dev, stream); break;
+            case 1: rc = launch_wgrad_group<2, 1>(h->v[v], dev, stream); break;
+            case 2: rc = launch_wgrad_group<4, 1>(h->v[v], dev, stream); break;
+            case 3: rc = launch_wgrad_group<1, 3>(h->v[v], dev, stream); break;
+            default: rc = launch_wgrad_group<2, 5>(h->v[v], dev, stream); break;
+        }
+        if (rc) return rc;
+    }
+    return DDPM_OK;
 }

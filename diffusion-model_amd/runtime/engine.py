@@ -106,6 +106,11 @@ class UNetEngine:
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
+        self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together
+        self._pin_eager: Optional[Tensor] = None      # pinned staging of the grouped-launch tables (eager steps reuse one)
+        self._pin_event = None
+        self._pin_spare: Optional[Tensor] = None      # handed to a graph capture, which then owns it for good
+        self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
         self._reduce_tables: Dict[Tuple[int, int, int], Tuple[Tensor, int, int, int]] = {}
@@ -186,6 +191,7 @@ class UNetEngine:
         part_ws: List[Optional[Tensor]] = [None]
         rkey = (n, h, w)
 
+        pending: List = []                            # deferred weight-gradient problems: (descriptor, cost, tensors kept alive)
         first_time: List[Tuple[Tensor, int]] = []     # (separately allocated piece, its offset) until the total is known
 
         def part_alloc(numel: int) -> Tuple[Tensor, int]:
@@ -218,7 +224,11 @@ class UNetEngine:
                 return
             numel = gw.numel()
             buf, off = part_alloc(splits * numel)
-            ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale, part=buf)
+            if self.group_wgrad:
+                pending.append((ops.wgrad_desc(kind, x0t, dyt, cout, None, buf, x1, in_add, in_mask, mscale),
+                                ops.wgrad_cost(kind, x0t, dyt, cout, x1), (x0t, dyt, x1, in_add, in_mask, buf)))
+            else:
+                ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale, part=buf)
             dst = G.offset(name + ".weight")
             for c0 in range(0, numel, 4096):
                 part_entries.append((off + c0, dst + c0, splits, numel, min(4096, numel - c0)))
@@ -422,6 +432,9 @@ class UNetEngine:
             tape.append(bwd_head)
 
             def finish():
+                if pending:
+                    self._launch_wgrad_group(pending, dev)
+                    pending.clear()
                 if rkey not in self._reduce_tables:
                     tab = ops.reduce_table(part_entries, dev)
                     self._reduce_tables[rkey] = (tab, len(part_entries), max(e[4] for e in part_entries), part_cursor[0])
@@ -432,6 +445,41 @@ class UNetEngine:
                 ops.reduce_rows(part_ws[0], G.flat, tab, ne, mw)
             return out, (tape, out_holder, finish)
         return out, None
+
+    def _launch_wgrad_group(self, pending, dev) -> None:
+        """All deferred dense weight gradients in at most five launches.  The problem tables are built on the host,
+        staged in pinned memory and copied to the device on the launch stream; under graph capture the copy becomes a
+        graph node that re-reads the pinned buffer at every replay, so that buffer is never reused afterwards."""
+        n = len(pending)
+        arr = (hip.WgradDesc * n)(*[p[0] for p in pending])
+        nbytes = int(hip.lib().ddpm_conv_wgrad_group_bytes(n))
+        pinned = lambda: torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)                # noqa: E731
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            host = self._pin_spare if self._pin_spare is not None and self._pin_spare.numel() >= nbytes else pinned()
+            self._pin_spare = None
+            self._pin_captured.append(host)
+        else:
+            if self._pin_eager is None or self._pin_eager.numel() < nbytes:
+                self._pin_eager = pinned()
+            elif self._pin_event is not None:
+                self._pin_event.synchronize()          # the previous step's copy must have read the buffer
+            host = self._pin_eager
+            if self._pin_spare is None or self._pin_spare.numel() < nbytes:
+                self._pin_spare = pinned()
+        hip.call("ddpm_conv_wgrad_group_plan", arr, n, host.data_ptr(), nbytes)
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        blob.copy_(host[:nbytes], non_blocking=True)
+        if not capturing:
+            self._pin_event = torch.cuda.Event()
+            self._pin_event.record()
+
+        def cost():
+            cs = [p[1]() for p in pending]
+            return sum(c[0] for c in cs), sum(c[1] for c in cs), f"{n} problems"
+
+        ops._launch("conv_wgrad_group_kernel", cost,
+                    lambda: hip.call("ddpm_conv_wgrad_group_launch", host.data_ptr(), blob.data_ptr(), hip.stream()))
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor]) -> Dict[str, Tensor]:

@@ -47,15 +47,19 @@ class GraphedTrainStep:
         self.graph2 = None
         if use_graph:
             self.optimizer.zero_grad(set_to_none=True)
+            # "thread_local": helper threads of the process (the collective library's watchdog polling its events) must not
+            # invalidate the capture; kernels launched by the autograd thread are captured all the same (capture is per stream)
+            torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._front()
                 if self.after_backward is None:
                     self._back()
             if self.after_backward is not None:
                 self.after_backward()
+                torch.cuda.synchronize()
                 self.graph2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph2):
+                with torch.cuda.graph(self.graph2, capture_error_mode="thread_local"):
                     self._back()
 
     def _front(self):
@@ -107,8 +111,9 @@ class GraphedSampler:
             self._body()
         torch.cuda.current_stream().wait_stream(s)
         if use_graph:
+            torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad():
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
                 self._body()
 
     def _body(self):

@@ -92,6 +92,9 @@ _PROTOS = {
     "ddpm_remap": ([_vp, _vp, _i, _i, _vp], _i),
     "ddpm_remap_chunk_elems": ([], _i),
     "ddpm_conv_wgrad_splits": ([_vp], _i),
+    "ddpm_conv_wgrad_group_bytes": ([_i], _i64),
+    "ddpm_conv_wgrad_group_plan": ([_vp, _i, _vp, _i64], _i),
+    "ddpm_conv_wgrad_group_launch": ([_vp, _vp, _vp], _i),
     "ddpm_sir_supported": ([_i, _i, _i, _i, _i, _i], _i),
     "ddpm_sir_forward": ([_vp, _vp], _i),
     "ddpm_sir_workgroups": ([_i, _i], _i),

@@ -165,6 +165,14 @@ typedef struct ddpm_wgrad_desc {
 } ddpm_wgrad_desc;
 
 int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream);
+/* Many weight-gradient problems in one launch per kernel variant (at most five launches).  A weight gradient is a leaf of
+ * the backward pass (base_trainer.py:214 only needs them before optimizer.step), so a caller can defer all of a
+ * network's to the end of backward.  plan() fills a host blob of ddpm_conv_wgrad_group_bytes(n) bytes from n descriptors;
+ * the caller copies the blob to device memory (same bytes) and passes both to launch().  Descriptors, tensors and the
+ * device blob must stay valid until the launches have run. */
+int64_t ddpm_conv_wgrad_group_bytes(int n);
+int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, void* host_blob, int64_t bytes);
+int ddpm_conv_wgrad_group_launch(const void* host_blob, const void* dev_blob, ddpm_stream_t stream);
 int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d);   /* rows of `part` for this problem (shape fields only are read); -1 on error */
 
 /* db[C] += column sums of an NHWC bf16 tensor [rows][cs] (first C channels); fp32 atomics. */

@@ -314,5 +314,10 @@ def test_graphed_train_step_with_gradient_hook(dev):
         w0 = [p.detach().clone() for p in m2.parameters()]
         step2.replay(); step2.replay()
         assert all(torch.equal(p.detach(), w) for p, w in zip(m2.parameters(), w0))
+    except BaseException as exc:                      # surface the failure even if tearing the process group down aborts
+        import traceback
+        traceback.print_exc()
+        raise exc
     finally:
+        torch.cuda.synchronize()
         td.destroy_process_group()
