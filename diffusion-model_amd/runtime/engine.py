@@ -106,6 +106,7 @@ class UNetEngine:
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
+        self.fuse_embed = True          # all time-embedding MLPs in one forward and one backward launch
         self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together
         self._pin_eager: Optional[Tensor] = None      # pinned staging of the grouped-launch tables (eager steps reuse one)
         self._pin_event = None
@@ -390,12 +391,42 @@ class UNetEngine:
         sin_v = Var(sin, need_grad=False)
 
         e, d = "encoder.", "decoder."
+        # ---- time-embedding MLPs: they depend on t only, so all of them run here in one launch; their backward runs
+        #      once at the end of the backward pass, when every stage-input gradient sum exists
+        enames = [f"{e}t_embeddings.{i}." for i in range(nst)] + [f"{d}t_embeddings.{i}." for i in range(nst)]
+        ewidths = [P[q + "layers.2.bias"].shape[0] for q in enames]
+        temb_vars: Dict[str, Var] = {}
+        late: List[Callable[[], None]] = []
+        if (self.fuse_embed and sp.t_dim == 32 and len(enames) <= hip.EMBED_MAX and all(32 <= c <= 512 and c % 32 == 0 for c in ewidths)
+                and all(P[q + "layers.0.bias"].shape[0] == 2 * c for q, c in zip(enames, ewidths))):
+            outs, esaved = ops.embed_forward(sin, [wc.fwd[q + "layers.0"] for q in enames], [P[q + "layers.0.bias"] for q in enames],
+                                             [wc.fwd[q + "layers.2"] for q in enames], [P[q + "layers.2.bias"] for q in enames], sp.act,
+                                             record=tape is not None)
+            for q, o in zip(enames, outs):
+                temb_vars[q] = Var(o)
+            if tape is not None:
+                def bwd_embed():
+                    tiles = (n + 31) // 32
+                    db1s, db0s = [], []
+                    for q, c in zip(enames, ewidths):
+                        b1, o1 = part_alloc(tiles * c)
+                        part_entries.append((o1, G.offset(q + "layers.2.bias"), tiles, c, c))
+                        b0, o0 = part_alloc(tiles * 2 * c)
+                        part_entries.append((o0, G.offset(q + "layers.0.bias"), tiles, 2 * c, 2 * c))
+                        db1s.append(b1); db0s.append(b0)
+                    dts = [temb_vars[q].g for q in enames]
+                    dt16s, dzs = ops.embed_backward(dts, [sv_[0] for sv_ in esaved], [wc.dgrad[q + "layers.2"] for q in enames], sp.act,
+                                                    db1s, db0s)
+                    for q, c, sv_, d16, dz_ in zip(enames, ewidths, esaved, dt16s, dzs):
+                        wgrad(K11, sv_[1], d16, c, q + "layers.2")
+                        wgrad(K11, sin, dz_, 2 * c, q + "layers.0")
+                late.append(bwd_embed)
         z = conv_unit(e + "stem_layers.0", Var(xin, need_grad=False), act=sp.act)
         tap("enc.stem", z.v)
         skips: List[Var] = []
         for i in range(nst):
             b = f"{e}layers.{i}.layers."
-            temb = embed(f"{e}t_embeddings.{i}.", sin_v)
+            temb = temb_vars.get(f"{e}t_embeddings.{i}.") or embed(f"{e}t_embeddings.{i}.", sin_v)
             a = conv_unit(b + "0.0", z, in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
             a = sir(b + "1.", a)
             a = sir(b + "2.", a)
@@ -408,7 +439,7 @@ class UNetEngine:
         tap("dec.input", z.v)
         for i in range(nst):
             b = f"{d}layers.{i}.layers."
-            temb = embed(f"{d}t_embeddings.{i}.", sin_v)
+            temb = temb_vars.get(f"{d}t_embeddings.{i}.") or embed(f"{d}t_embeddings.{i}.", sin_v)
             a = conv_unit(b + "0.0", z, x1=skips[nst - 1 - i], in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
             a = sir(b + "1.", a)
             a = conv_unit(b + "2.0", a, norm=b + "2.1", groups=sp.groups, act=sp.act)
@@ -432,6 +463,8 @@ class UNetEngine:
             tape.append(bwd_head)
 
             def finish():
+                for fn in late:
+                    fn()
                 if pending:
                     self._launch_wgrad_group(pending, dev)
                     pending.clear()

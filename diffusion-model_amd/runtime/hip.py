@@ -52,6 +52,20 @@ class SirBwdDesc(C.Structure):
         ("mask_scale", _f)] + [(k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act")]
 
 
+EMBED_MAX = 8
+_vp8, _i8 = _vp * EMBED_MAX, C.c_int32 * EMBED_MAX
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("sin", _vp), ("N", C.c_int32), ("t_dim", C.c_int32), ("act", C.c_int32), ("nmlp", C.c_int32), ("C", _i8),
+                ("w0", _vp8), ("b0", _vp8), ("w1", _vp8), ("b1", _vp8), ("out", _vp8), ("raw0", _vp8), ("h", _vp8)]
+
+
+class EmbedBwdDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("act", C.c_int32), ("nmlp", C.c_int32), ("pad", C.c_int32), ("C", _i8),
+                ("dtemb", _vp8), ("raw0", _vp8), ("w1d", _vp8), ("dt16", _vp8), ("dz", _vp8), ("db1", _vp8), ("db0", _vp8)]
+
+
 class ReduceEntry(C.Structure):
     _fields_ = [("src_off", _i64), ("dst_off", _i64), ("rows", C.c_int32), ("row_stride", C.c_int32), ("width", C.c_int32),
                 ("pad", C.c_int32)]
@@ -95,6 +109,8 @@ _PROTOS = {
     "ddpm_conv_wgrad_group_bytes": ([_i], _i64),
     "ddpm_conv_wgrad_group_plan": ([_vp, _i, _vp, _i64], _i),
     "ddpm_conv_wgrad_group_launch": ([_vp, _vp, _vp], _i),
+    "ddpm_embed_forward": ([_vp, _vp], _i),
+    "ddpm_embed_backward": ([_vp, _vp], _i),
     "ddpm_sir_supported": ([_i, _i, _i, _i, _i, _i], _i),
     "ddpm_sir_forward": ([_vp, _vp], _i),
     "ddpm_sir_workgroups": ([_i, _i], _i),

@@ -162,6 +162,54 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
     return out
 
 
+def _ptr_array(tensors):
+    arr = (C.c_void_p * hip.EMBED_MAX)()
+    for i, t in enumerate(tensors):
+        arr[i] = hip.ptr(t)
+    return arr
+
+
+def embed_forward(sin: Tensor, w0s, b0s, w1s, b1s, act: int, record: bool):
+    """All time-embedding MLPs in one launch.  sin: bf16 [N,1,1,32]; w0s[i]: bf16 [1][2C][32], w1s[i]: bf16 [1][C][2C].
+    Returns (outs: list of fp32 [N][C], saved: list of (raw0, h) bf16 [N,1,1,2C] or None)."""
+    n, t_dim = sin.shape[0], sin.shape[-1]
+    k = len(w0s)
+    cs = [b.shape[0] for b in b1s]
+    assert k <= hip.EMBED_MAX and all(w.shape[-2:] == (2 * c, t_dim) for w, c in zip(w0s, cs)) and all(w.shape[-2:] == (c, 2 * c) for w, c in zip(w1s, cs))
+    outs = [torch.empty(n, c, device=sin.device, dtype=torch.float32) for c in cs]
+    saved = [(torch.empty(n, 1, 1, 2 * c, device=sin.device, dtype=BF16), torch.empty(n, 1, 1, 2 * c, device=sin.device, dtype=BF16))
+             for c in cs] if record else None
+    d = hip.EmbedDesc(sin=hip.ptr(sin), N=n, t_dim=t_dim, act=act, nmlp=k)
+    for i, c in enumerate(cs):
+        d.C[i] = c
+    d.w0, d.b0, d.w1, d.b1, d.out = _ptr_array(w0s), _ptr_array(b0s), _ptr_array(w1s), _ptr_array(b1s), _ptr_array(outs)
+    if record:
+        d.raw0, d.h = _ptr_array([s[0] for s in saved]), _ptr_array([s[1] for s in saved])
+    _launch("embed_fwd_kernel", lambda: (_nb(sin, *w0s, *w1s, *outs) + (sum(_nb(*s) for s in saved) if saved else 0),
+                                         sum(2.0 * n * (t_dim * 2 * c + 2 * c * c) for c in cs), f"{k} MLPs"),
+            lambda: hip.call("ddpm_embed_forward", C.byref(d), hip.stream()))
+    return outs, saved
+
+
+def embed_backward(dtembs, raw0s, w1ds, act: int, db1s, db0s):
+    """Backward data path of all MLPs in one launch.  Returns (dt16s: bf16 [N,1,1,C], dzs: bf16 [N,1,1,2C])."""
+    n = dtembs[0].shape[0]
+    cs = [g.shape[1] for g in dtembs]
+    dev = dtembs[0].device
+    dt16s = [torch.empty(n, 1, 1, c, device=dev, dtype=BF16) for c in cs]
+    dzs = [torch.empty(n, 1, 1, 2 * c, device=dev, dtype=BF16) for c in cs]
+    d = hip.EmbedBwdDesc(N=n, act=act, nmlp=len(cs), pad=0)
+    for i, c in enumerate(cs):
+        d.C[i] = c
+        assert dtembs[i].dtype == torch.float32 and dtembs[i].is_contiguous() and w1ds[i].shape[-2:] == (2 * c, c)
+        assert db1s[i].numel() == (n + 31) // 32 * c and db0s[i].numel() == (n + 31) // 32 * 2 * c
+    d.dtemb, d.raw0, d.w1d, d.dt16, d.dz = _ptr_array(dtembs), _ptr_array(raw0s), _ptr_array(w1ds), _ptr_array(dt16s), _ptr_array(dzs)
+    d.db1, d.db0 = _ptr_array(db1s), _ptr_array(db0s)
+    _launch("embed_bwd_kernel", lambda: (_nb(*dtembs, *raw0s, *w1ds, *dt16s, *dzs), sum(4.0 * n * c * c for c in cs), f"{len(cs)} MLPs"),
+            lambda: hip.call("ddpm_embed_backward", C.byref(d), hip.stream()))
+    return dt16s, dzs
+
+
 def sir_supported(c: int, h: int, w: int, e: int, groups: int, act: int) -> bool:
     return bool(hip.lib().ddpm_sir_supported(c, h, w, e, groups, act))
 

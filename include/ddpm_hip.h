@@ -259,6 +259,37 @@ typedef struct ddpm_sir_bwd_desc {
 int ddpm_sir_workgroups(int HW, int N);
 int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t stream);
 
+/* ---- all time-embedding MLPs of the network in one launch (embed_mlp.hip) --------------------------------------
+ * EmbedBlock (constituent_blocks.py:282-328): out_i = Linear_1(act(Linear_0(sin))) for every stage i, sin = the
+ * sinusoidal embedding [N][t_dim] bf16 (ddpm_time_embedding), t_dim = 32.  Width C[i], hidden width 2*C[i].
+ * w0: bf16 [2C][t_dim], w1: bf16 [C][2C] (forward weight-copy layout), biases fp32, out: fp32 [N][C] (the operand of
+ * ddpm_conv_desc.in_add).  raw0/h: optional saved tensors for training (bf16 [N][2C]: hidden pre-activation and
+ * activation). */
+#define DDPM_EMBED_MAX 8
+typedef struct ddpm_embed_desc {
+    const void* sin;
+    int32_t N, t_dim, act, nmlp;
+    int32_t C[DDPM_EMBED_MAX];
+    const void* w0[DDPM_EMBED_MAX]; const float* b0[DDPM_EMBED_MAX];
+    const void* w1[DDPM_EMBED_MAX]; const float* b1[DDPM_EMBED_MAX];
+    float* out[DDPM_EMBED_MAX];
+    void* raw0[DDPM_EMBED_MAX]; void* h[DDPM_EMBED_MAX];
+} ddpm_embed_desc;
+int ddpm_embed_forward(const ddpm_embed_desc* d, ddpm_stream_t stream);
+
+/* Data path of the backward of all MLPs: dtemb fp32 [N][C] (gradient of out_i) -> dt16 (its bf16 copy, the dY operand of the
+ * second layer's weight gradient) and dz bf16 [N][2C] (gradient of the hidden pre-activation, the dY operand of the first
+ * layer's weight gradient); w1d: bf16 [2C][C] (data-gradient weight-copy layout).  db1 [ceil(N/32)][C] and db0
+ * [ceil(N/32)][2C] receive per-row-tile bias-gradient partial sums for ddpm_reduce_rows. */
+typedef struct ddpm_embed_bwd_desc {
+    int32_t N, act, nmlp, pad;
+    int32_t C[DDPM_EMBED_MAX];
+    const float* dtemb[DDPM_EMBED_MAX]; const void* raw0[DDPM_EMBED_MAX]; const void* w1d[DDPM_EMBED_MAX];
+    void* dt16[DDPM_EMBED_MAX]; void* dz[DDPM_EMBED_MAX];
+    float* db1[DDPM_EMBED_MAX]; float* db0[DDPM_EMBED_MAX];
+} ddpm_embed_bwd_desc;
+int ddpm_embed_backward(const ddpm_embed_bwd_desc* d, ddpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
