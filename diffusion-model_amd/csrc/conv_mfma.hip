@@ -15,6 +15,8 @@
 #include "conv_geom.h"
 #include "ddpm_hip.h"
 
+int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_small.hip
+
 struct ConvArgs {
     ConvGeom g;
     const bf16* in0; const bf16* in1; int C0, C1;
@@ -285,6 +287,8 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
+    // 3x3 convolutions on 2x2 / 4x4 images (the deepest stages) have their own kernel
+    if (const int rc = ddpm_conv_small_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
 
     ConvArgs a;
     // Tile choice.  Workgroup = 4 waves as WM x WN; tile = (32*WM) positions x (32*NT*WN) output channels.
