@@ -286,6 +286,12 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     p.maxi = (a.g.max_taps * nco + 3) / 4;
     long long other = (long long)cob * nci * a.g.ncls;
     long long msplit = 512 / other;
+    if (d->tiles_per_split > 0) {
+        // grouped launches fill the machine with many problems at once: fewer, longer position splits mean fewer
+        // partial tiles to store and to fold afterwards
+        const long long want = (a.ntiles + d->tiles_per_split - 1) / d->tiles_per_split;
+        if (want < msplit) msplit = want;
+    }
     if (msplit < 1) msplit = 1;
     if (msplit > a.ntiles) msplit = a.ntiles;
     const int npix = a.g.NB * a.g.PH * a.g.PW;

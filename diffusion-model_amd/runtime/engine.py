@@ -107,6 +107,7 @@ class UNetEngine:
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
         self.fuse_embed = True          # all time-embedding MLPs in one forward and one backward launch
+        self.wgrad_tiles_per_split = 8  # grouped weight gradients: 128-position tiles per position split
         self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together
         self._pin_eager: Optional[Tensor] = None      # pinned staging of the grouped-launch tables (eager steps reuse one)
         self._pin_event = None
@@ -219,14 +220,19 @@ class UNetEngine:
             """dense weight gradient: every position split stores its partial tile (no atomics on the few hot cache lines
             of a small weight block); the end-of-backward reduction folds the rows into the gradient buffer"""
             gw = G[name + ".weight"]
-            splits = ops.conv_wgrad_splits(kind, x0t, dyt, cout, x1=x1)
-            if splits <= 1:
+            tps = self.wgrad_tiles_per_split if self.group_wgrad else 0
+            splits = ops.conv_wgrad_splits(kind, x0t, dyt, cout, x1=x1, tiles_per_split=tps)
+            if splits <= 1 and not self.group_wgrad:
                 ops.conv_wgrad(kind, x0t, dyt, cout, gw, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale)
+                return
+            if splits <= 1:              # single split: it adds straight into the gradient buffer (no contention)
+                pending.append((ops.wgrad_desc(kind, x0t, dyt, cout, gw, None, x1, in_add, in_mask, mscale, tps),
+                                ops.wgrad_cost(kind, x0t, dyt, cout, x1), (x0t, dyt, x1, in_add, in_mask, gw)))
                 return
             numel = gw.numel()
             buf, off = part_alloc(splits * numel)
             if self.group_wgrad:
-                pending.append((ops.wgrad_desc(kind, x0t, dyt, cout, None, buf, x1, in_add, in_mask, mscale),
+                pending.append((ops.wgrad_desc(kind, x0t, dyt, cout, None, buf, x1, in_add, in_mask, mscale, tps),
                                 ops.wgrad_cost(kind, x0t, dyt, cout, x1), (x0t, dyt, x1, in_add, in_mask, buf)))
             else:
                 ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale, part=buf)

@@ -81,7 +81,7 @@ class WgradDesc(C.Structure):
         ("kind", _i), ("N", _i), ("IH", _i), ("IW", _i),
         ("in0", _vp), ("in1", _vp), ("C0", _i), ("C1", _i),
         ("in_add", _vp), ("in_mask", _vp), ("in_mask_scale", _f),
-        ("dy", _vp), ("Cout", _i), ("dy_cs", _i), ("dw", _vp), ("part", _vp),
+        ("dy", _vp), ("Cout", _i), ("dy_cs", _i), ("dw", _vp), ("part", _vp), ("tiles_per_split", _i),
     ]
 
 

@@ -81,18 +81,18 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     return out
 
 
-def wgrad_desc(kind, x0, dy, cout, dw, part, x1, in_add, in_mask, in_scale):
+def wgrad_desc(kind, x0, dy, cout, dw, part, x1, in_add, in_mask, in_scale, tiles_per_split=0):
     """ddpm_wgrad_desc of one weight-gradient problem (the caller keeps the tensors alive)"""
     n, ih, iw, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     return hip.WgradDesc(kind=kind, N=n, IH=ih, IW=iw, in0=hip.ptr(x0), in1=hip.ptr(x1), C0=c0, C1=c1, in_add=hip.ptr(in_add),
                          in_mask=hip.ptr(in_mask), in_mask_scale=in_scale, dy=hip.ptr(dy), Cout=cout, dy_cs=dy.shape[3], dw=hip.ptr(dw),
-                         part=hip.ptr(part))
+                         part=hip.ptr(part), tiles_per_split=tiles_per_split)
 
 
-def conv_wgrad_splits(kind: int, x0: Tensor, dy: Tensor, cout: int, *, x1: Optional[Tensor] = None) -> int:
+def conv_wgrad_splits(kind: int, x0: Tensor, dy: Tensor, cout: int, *, x1: Optional[Tensor] = None, tiles_per_split: int = 0) -> int:
     """Number of partial-sum rows conv_wgrad(part=...) writes for this problem."""
-    d = wgrad_desc(kind, x0, dy, cout, None, None, x1, None, None, 1.0)
+    d = wgrad_desc(kind, x0, dy, cout, None, None, x1, None, None, 1.0, tiles_per_split)
     r = hip.lib().ddpm_conv_wgrad_splits(C.byref(d))
     if r < 0:
         raise RuntimeError(hip.lib().ddpm_last_error().decode())
@@ -110,7 +110,7 @@ def wgrad_cost(kind, x0, dy, cout, x1=None):
 
 def conv_wgrad(kind: int, x0: Tensor, dy: Tensor, cout: int, dw: Optional[Tensor], *, x1: Optional[Tensor] = None,
                in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0,
-               part: Optional[Tensor] = None) -> Optional[Tensor]:
+               part: Optional[Tensor] = None, tiles_per_split: int = 0) -> Optional[Tensor]:
     """Weight gradient.  x0/x1: the forward inputs; dy: NHWC bf16.  Either dw (fp32 [slices][cout][C0+C1], kernel layout)
     += gradient with atomics, or - when `part` (fp32 [splits][slices][cout][C0+C1]) is given - every position split stores
     its partial sums there for a later reduce_rows pass."""
@@ -119,7 +119,7 @@ def conv_wgrad(kind: int, x0: Tensor, dy: Tensor, cout: int, dw: Optional[Tensor
     assert dy.dtype == BF16 and dy.is_contiguous()
     if part is None:
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape[1] == cout and dw.shape[2] == c0 + c1, (tuple(dw.shape), cout, c0, c1)
-    d = wgrad_desc(kind, x0, dy, cout, dw, part, x1, in_add, in_mask, in_scale)
+    d = wgrad_desc(kind, x0, dy, cout, dw, part, x1, in_add, in_mask, in_scale, tiles_per_split)
     oh, ow = dy.shape[1], dy.shape[2]
     _launch("conv_wgrad_kernel", lambda: (_nb(x0, x1, in_add, in_mask, dy) + 4 * _SLICES[kind] * cout * (c0 + c1),
                                           2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}"),

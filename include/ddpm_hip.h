@@ -162,6 +162,8 @@ typedef struct ddpm_wgrad_desc {
     float* part;              /* optional fp32 [ddpm_conv_wgrad_splits(d)][slices][Cout][C0+C1]: when set, every position split
                                * stores its partial sums there (each element written exactly once, no atomics) and the caller
                                * folds the rows into dw with ddpm_reduce_rows */
+    int tiles_per_split;      /* 0: split the positions for a standalone launch (about 512 workgroups); > 0: at least this many
+                               * 128-position tiles per split (grouped launches: fewer partial rows) */
 } ddpm_wgrad_desc;
 
 int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream);
