@@ -234,12 +234,175 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgradArgs* 
         if (first[mid] <= b) lo = mid; else hi = mid;
     }
     lo = __builtin_amdgcn_readfirstlane(lo);
-    const WgradArgs& a = tab[lo];
+    // the problem description moves to LDS once: read through a reference into global memory it would be fetched
+    // again after every store (the tap tables are indexed at run time, so registers are no option either)
+    constexpr int ARGS_BYTES = (sizeof(WgradArgs) + 15) & ~15;
+    {
+        const int* src = (const int*)(tab + lo);
+        int* dst = (int*)smem;
+        for (int i = threadIdx.x; i < (int)(sizeof(WgradArgs) / 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const WgradArgs& a = *(const WgradArgs*)smem;
     const int local = b - first[lo];
     const int gx = a.gx, gy = a.gy;
     const int bx = local % gx, r = local / gx;
-    wgrad_body<NCO, MAXI>(a, bx, r % gy, r / gy, gx, smem);
+    wgrad_body<NCO, MAXI>(a, bx, r % gy, r / gy, gx, smem + ARGS_BYTES);
 }
+
+
+// ---- pointwise (1x1 / Linear) weight gradient ---------------------------------------------------------------------
+// dW[co][ci] = sum over rows of dY[row][co] * X[row][ci]: no patches, no halo, rows contiguous in memory.  Two thirds
+// of the network's weight-gradient problems have this form, and for them the tap-list kernel's per-tile pixel tables
+// and single-buffered staging are pure overhead.  A workgroup owns up to 128 output x 128 input channels (16 tiles of
+// 32x32 dealt to the 4 waves) and a contiguous range of rows, streamed in chunks of 64 through a double-buffered LDS
+// stage: the global loads of chunk c+1 are in flight while the MFMAs of chunk c run, one barrier per chunk.
+struct PwArgs {
+    const bf16* x; const bf16* dy; const unsigned char* in_mask; float in_mask_scale;
+    float* dw; float* part; long long dw_numel;
+    long long R, rows_per_split;
+    int Cin, Cout, dy_cs;
+    int gx, nib;              // position splits; input-channel blocks (blockIdx.y = cb * nib + ib)
+};
+
+#define PW_ROWS 64
+#define PW_RS 272             // LDS row stride in bytes: 128 channels + 16 bytes of padding
+
+__device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int by, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = by / a.nib, ib = by - cb * a.nib;
+    const int co0 = cb * 128, ci0 = ib * 128;
+    const int cow = min(128, ((a.Cout - co0) + 31) & ~31), ciw = min(128, a.Cin - ci0);
+    const int nct = cow / 32, nit = ciw / 32, npairs = nct * nit;
+    const int xv = ciw / 8, dv = cow / 8;                   // 16-byte vectors per row of each operand
+    const int nx = PW_ROWS * xv, nitems = nx + PW_ROWS * dv; // <= 2048 vectors per chunk
+    const long long r_begin = (long long)bx * a.rows_per_split;
+    const long long r_end = min(a.R, r_begin + a.rows_per_split);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int kq = 8 * (grp >> 1) + q;
+    const int colb = (16 * (grp & 1) + 4 * pp) * 2;
+
+    // per-thread slots of a chunk (the same for every chunk): row, global element offset inside the chunk, LDS offset;
+    // computed once - the integer divisions would otherwise cost more than the MFMAs of a chunk
+    bf16x8 v[8];
+    int s_row[8], s_goff[8], s_lds[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int it = tid + u * 256;
+        s_row[u] = -1; s_goff[u] = 0; s_lds[u] = 0;
+        if (it < nx) {
+            const int row = it / xv, c = (it - row * xv) * 8;
+            s_row[u] = row; s_goff[u] = row * a.Cin + ci0 + c; s_lds[u] = row * PW_RS + c * 2;
+        } else if (it < nitems) {
+            const int di = it - nx;
+            const int row = di / dv, c = (di - row * dv) * 8;
+            if (co0 + c + 8 <= a.dy_cs) { s_row[u] = row | 0x10000; s_goff[u] = row * a.dy_cs + co0 + c; }
+            else s_row[u] = -2;                                    // padded output channels: zeros
+            s_lds[u] = (PW_ROWS + row) * PW_RS + c * 2;
+        }
+    }
+    const bf16* xg = a.x;
+    const bf16* dg = a.dy;
+    const unsigned char* mg = a.in_mask;
+    const float mscale = a.in_mask_scale;
+    const long long x_rs = a.Cin, d_rs = a.dy_cs;
+    auto fetch = [&](long long r0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+            if (s_row[u] < 0) continue;
+            const int row = s_row[u] & 0xFFFF;
+            if (r0 + row >= r_end) continue;
+            if (s_row[u] & 0x10000) {
+                v[u] = *(const bf16x8*)(dg + r0 * d_rs + s_goff[u]);
+            } else {
+                const long long e = r0 * x_rs + s_goff[u];
+                v[u] = *(const bf16x8*)(xg + e);
+                if (mg) {
+                    const unsigned m = mg[e >> 3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[u][j] = (m >> j) & 1 ? (bf16)((float)v[u][j] * mscale) : (bf16)0.f;
+                }
+            }
+        }
+    };
+    auto stash = [&](char* b) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s_row[u] != -1) *(bf16x8*)(b + s_lds[u]) = v[u];
+    };
+
+    if (r_begin < r_end) fetch(r_begin);
+    int par = 0;
+    for (long long r0 = r_begin; r0 < r_end; r0 += PW_ROWS, par ^= 1) {
+        char* b = smem + par * (2 * PW_ROWS * PW_RS);       // each buffer: X rows, then dY rows
+        stash(b);
+        if (r0 + PW_ROWS < r_end) fetch(r0 + PW_ROWS);
+        __syncthreads();
+        const char* sx = b;
+        const char* sd = b + PW_ROWS * PW_RS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pr = wave + 4 * i;
+            if (pr < npairs) {
+                const int ct = pr / nit, itile = pr - ct * nit;
+                const char* dyp = sd + ct * 64 + colb;
+                const char* xp = sx + itile * 64 + colb;
+#pragma unroll
+                for (int ks = 0; ks < PW_ROWS / 16; ++ks) {
+                    const int k = ks * 16 + kq;
+                    const bf16x8 av = tr_frag(dyp + k * PW_RS, dyp + (k + 4) * PW_RS);
+                    const bf16x8 bv = tr_frag(xp + k * PW_RS, xp + (k + 4) * PW_RS);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pr = wave + 4 * i;
+        if (pr >= npairs) continue;
+        const int ct = pr / nit, itile = pr - ct * nit;
+        const int ci = ci0 + itile * 32 + (lane & 31);
+        float* base = a.part ? a.part + (long long)bx * a.dw_numel : a.dw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < a.Cout && ci < a.Cin) {
+                if (a.part) base[(long long)co * a.Cin + ci] = acc[i][r];
+                else atomicAdd(base + (long long)co * a.Cin + ci, acc[i][r]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    pw_body(a, blockIdx.x, blockIdx.y, smem);
+}
+
+__global__ __launch_bounds__(256) void pw_wgrad_group_kernel(const PwArgs* __restrict__ tab, const int* __restrict__ first, const int n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (first[mid] <= b) lo = mid; else hi = mid;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const PwArgs a = tab[lo];          // by value: a reference into global memory would be re-read around every store
+    const int local = b - first[lo];
+    pw_body(a, local % a.gx, local / a.gx, smem);
+}
+
+#define PW_LDS (4 * PW_ROWS * PW_RS)
 
 template <int NCO, int MAXI>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
@@ -254,6 +417,8 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s
 
 struct WgradPlan {
     WgradArgs a;
+    PwArgs pw;
+    bool pointwise;
     int nco, maxi;
     dim3 grid;
     size_t lds;
@@ -277,6 +442,33 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     const int Cin = d->C0 + d->C1;
     const int slices = d->kind == CONV_1X1 ? 1 : d->kind == CONVT_2X2_S2 ? 4 : 9;
     a.dw_numel = (long long)slices * d->Cout * Cin;
+    p.pointwise = d->kind == CONV_1X1 && d->C1 == 0 && !d->in_add && Cin % 32 == 0;
+    if (p.pointwise) {
+        PwArgs& w = p.pw;
+        w.x = a.in0; w.dy = a.dy; w.in_mask = a.in_mask; w.in_mask_scale = a.in_mask_scale;
+        w.dw = a.dw; w.part = a.part; w.dw_numel = a.dw_numel;
+        w.R = (long long)d->N * d->IH * d->IW;
+        w.Cin = Cin; w.Cout = d->Cout; w.dy_cs = d->dy_cs;
+        const int ncb = (d->Cout + 127) / 128;
+        w.nib = (Cin + 127) / 128;
+        const long long other = (long long)ncb * w.nib;
+        const long long tiles = (w.R + 127) / 128;
+        long long msplit = 512 / other;
+        if (d->tiles_per_split > 0) {
+            const long long want = (tiles + d->tiles_per_split - 1) / d->tiles_per_split;
+            if (want < msplit) msplit = want;
+        }
+        if (msplit < 1) msplit = 1;
+        if (msplit > tiles) msplit = tiles;
+        w.rows_per_split = (tiles + msplit - 1) / msplit * 128;
+        msplit = (w.R + w.rows_per_split - 1) / w.rows_per_split;
+        w.gx = (int)msplit;
+        p.grid = dim3((unsigned)msplit, (unsigned)other, 1);
+        p.lds = PW_LDS;
+        p.nco = p.maxi = 0;
+        a.gx = (int)msplit; a.gy = (int)other;
+        return DDPM_OK;
+    }
     const int co_sub = (d->Cout + 31) / 32;
     int nco = a.g.max_taps >= 9 ? 2 : 4;
     if (nco > co_sub) nco = co_sub;
@@ -314,6 +506,16 @@ extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) 
     hipStream_t stream = (hipStream_t)stream_;
     WgradPlan p;
     if (int rc = wgrad_plan(d, p)) return rc;
+    if (p.pointwise) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)pw_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess)
+                return ddpm_check_launch("wgrad: raise dynamic LDS limit");
+            attr = true;
+        }
+        hipLaunchKernelGGL(pw_wgrad_kernel, p.grid, dim3(256), PW_LDS, stream, p.pw);
+        return ddpm_check_launch("pw_wgrad");
+    }
     const WgradArgs& a = p.a;
     const int nco = p.nco, maxi = p.maxi;
     const dim3 grid = p.grid;
@@ -329,9 +531,9 @@ extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) 
 // ---- grouped launch ---------------------------------------------------------------------------------------------
 // Blob layout (identical bytes on host and device): header, then per kernel variant the WgradArgs of its problems and
 // the prefix table of their workgroup counts.
-#define WG_VARIANTS 5
-static const int kVariantNco[WG_VARIANTS] = {1, 2, 4, 1, 2};
-static const int kVariantMaxi[WG_VARIANTS] = {1, 1, 1, 3, 5};
+#define WG_VARIANTS 6          // five tap-list kernel instances + the pointwise kernel (index 5)
+static const int kVariantNco[WG_VARIANTS] = {1, 2, 4, 1, 2, 0};
+static const int kVariantMaxi[WG_VARIANTS] = {1, 1, 1, 3, 5, 0};
 
 struct WgradGroupHeader {
     long long magic;
@@ -342,7 +544,7 @@ static inline long long align16(long long v) { return (v + 15) & ~15LL; }
 
 extern "C" int64_t ddpm_conv_wgrad_group_bytes(int n) {
     if (n < 0) n = 0;
-    return align16(sizeof(WgradGroupHeader)) + WG_VARIANTS * 16 + align16((long long)n * sizeof(WgradArgs)) +
+    return align16(sizeof(WgradGroupHeader)) + WG_VARIANTS * 32 + align16((long long)n * sizeof(WgradArgs)) +
            align16((long long)(n + WG_VARIANTS) * sizeof(int)) + 64;
 }
 
@@ -360,6 +562,7 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
         variant_of[i] = -1;
         for (int v = 0; v < WG_VARIANTS; ++v)
             if (plans[i].nco == kVariantNco[v] && plans[i].maxi == kVariantMaxi[v]) variant_of[i] = v;
+        if (plans[i].pointwise) variant_of[i] = 5;
         DDPM_REQUIRE(variant_of[i] >= 0, "wgrad group: no kernel for nco=%d items/wave=%d", plans[i].nco, plans[i].maxi);
     }
     long long off = align16(sizeof(WgradGroupHeader));
@@ -368,16 +571,17 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
         for (int i = 0; i < n; ++i) cnt += variant_of[i] == v;
         h->v[v].nprob = cnt;
         h->v[v].args_off = off;
-        off = align16(off + (long long)cnt * sizeof(WgradArgs));
+        off = align16(off + (long long)cnt * (v == 5 ? sizeof(PwArgs) : sizeof(WgradArgs)));
         h->v[v].first_off = off;
         off = align16(off + (long long)(cnt + 1) * sizeof(int));
         WgradArgs* args = (WgradArgs*)(base + h->v[v].args_off);
+        PwArgs* pargs = (PwArgs*)(base + h->v[v].args_off);
         int* first = (int*)(base + h->v[v].first_off);
         int k = 0, blocks = 0;
         long long lds = 0;
         for (int i = 0; i < n; ++i) {
             if (variant_of[i] != v) continue;
-            args[k] = plans[i].a;
+            if (v == 5) pargs[k] = plans[i].pw; else args[k] = plans[i].a;
             first[k] = blocks;
             blocks += (int)(plans[i].grid.x * plans[i].grid.y * plans[i].grid.z);
             if ((long long)plans[i].lds > lds) lds = (long long)plans[i].lds;
@@ -393,11 +597,11 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
 template <int NCO, int MAXI>
 static int launch_wgrad_group(const WgradGroupHeader::V& v, const char* dev, hipStream_t stream) {
     auto k = conv_wgrad_group_kernel<NCO, MAXI>;
-    if (v.lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds) != hipSuccess)
+    if (v.lds + sizeof(WgradArgs) + 16 > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(v.lds + sizeof(WgradArgs) + 16)) != hipSuccess)
             return ddpm_check_launch("wgrad group: raise dynamic LDS limit");
     }
-    hipLaunchKernelGGL(k, dim3(v.total_blocks), dim3(256), (size_t)v.lds, stream, (const WgradArgs*)(dev + v.args_off),
+    hipLaunchKernelGGL(k, dim3(v.total_blocks), dim3(256), (size_t)v.lds + ((sizeof(WgradArgs) + 15) & ~15), stream, (const WgradArgs*)(dev + v.args_off),
                        (const int*)(dev + v.first_off), v.nprob);
     return ddpm_check_launch("conv_wgrad_group");
 }
@@ -416,7 +620,18 @@ extern "C" int ddpm_conv_wgrad_group_launch(const void* host_blob, const void* d
             case 1: rc = launch_wgrad_group<2, 1>(h->v[v], dev, stream); break;
             case 2: rc = launch_wgrad_group<4, 1>(h->v[v], dev, stream); break;
             case 3: rc = launch_wgrad_group<1, 3>(h->v[v], dev, stream); break;
-            default: rc = launch_wgrad_group<2, 5>(h->v[v], dev, stream); break;
+            case 4: rc = launch_wgrad_group<2, 5>(h->v[v], dev, stream); break;
+            default: {
+                static bool attr = false;
+                if (!attr) {
+                    if (hipFuncSetAttribute((const void*)pw_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess)
+                        return ddpm_check_launch("wgrad group: raise dynamic LDS limit");
+                    attr = true;
+                }
+                hipLaunchKernelGGL(pw_wgrad_group_kernel, dim3(h->v[v].total_blocks), dim3(256), PW_LDS, stream,
+                                   (const PwArgs*)(dev + h->v[v].args_off), (const int*)(dev + h->v[v].first_off), h->v[v].nprob);
+                rc = ddpm_check_launch("pw_wgrad_group");
+            } break;
         }
         if (rc) return rc;
     }
