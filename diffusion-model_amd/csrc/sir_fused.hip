@@ -379,6 +379,275 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_fwd_kernel(const SirArgs a) {
     }
 }
 
+
+// Variant for images too large to keep both the block input and the expanded tensor in LDS (32x32 pixels at C = 32:
+// the expanded [1024][64] tile alone takes 144 KB).  One workgroup still owns one image; the expansion GEMM takes its
+// A fragments straight from global memory (each input element is used by exactly one fragment load), the projection
+// keeps all of a wave's output tiles in accumulators until every wave has finished reading the expanded tile, and then
+// reuses that LDS for the raw projection output.  Elementwise phases walk 16 vectors per thread.
+template <int C, int W, int ACT>
+__device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
+    constexpr int E = 2 * C, HW = W * W, M = HW;
+    constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
+    constexpr int NWV = SIR_THREADS / 64, MT = M / 32, TPW = MT / NWV;
+    static_assert(MT % NWV == 0 && C == 32, "big variant: one output-channel tile, M tiles dealt evenly");
+    using E1 = Ew<E, M>;
+    using E3 = Ew<C, M>;
+    char* s_e = smem;                              // [M][ES]; later [M][XS] raw projection output
+    float* s_part = (float*)(smem + M * ES);       // [waves][2][16]
+    float* s_mr = s_part + NWV * 2 * SIR_G;        // [16][2]
+    float* s_p = s_mr + 2 * SIR_G;
+    constexpr int P_BE = 0, P_G1 = E, P_B1 = 2 * E, P_BD = 3 * E, P_G2 = 4 * E, P_B2 = 5 * E, P_WD = 6 * E, P_BP = 15 * E,
+                  P_G3 = 15 * E + C, P_B3 = 15 * E + 2 * C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long n0 = blockIdx.x;
+    const long long row0 = n0 * HW;
+    const bool rec = a.raw_e != nullptr;
+
+    for (int i = tid; i < E; i += SIR_THREADS) {
+        s_p[P_BE + i] = a.be[i]; s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i];
+        s_p[P_BD + i] = a.bd[i]; s_p[P_G2 + i] = a.g2[i]; s_p[P_B2 + i] = a.b2[i];
+    }
+    for (int i = tid; i < 9 * E; i += SIR_THREADS) s_p[P_WD + i] = a.wd[i];
+    for (int i = tid; i < C; i += SIR_THREADS) { s_p[P_BP + i] = a.bp[i]; s_p[P_G3 + i] = a.g3[i]; s_p[P_B3 + i] = a.b3[i]; }
+
+    // ---- expand: A fragments from global memory (dropout of the block input applied to the fragment)
+    {
+        constexpr int KS = C / 16;
+        bf16x8 af[TPW][KS];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const long long e = (row0 + (wave + NWV * i) * 32 + (lane & 31)) * C + ks * 16 + (lane >> 5) * 8;
+                bf16x8 v = *(const bf16x8*)(a.x + e);
+                if (a.m_in) {
+                    const unsigned m = a.m_in[e >> 3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.mscale) : (bf16)0.f;
+                }
+                af[i][ks] = v;
+            }
+        __syncthreads();
+#pragma unroll 1
+        for (int nt = 0; nt < E / 32; ++nt) {
+            const int col = nt * 32 + (lane & 31);
+            bf16x8 bf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bf[ks] = *(const bf16x8*)(a.we + (long long)col * C + ks * 16 + (lane >> 5) * 8);
+            const float b = s_p[P_BE + col];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bf[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave + NWV * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    *(bf16*)(s_e + row * ES + col * 2) = (bf16)(acc[r] + b);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
+    bf16x8 xr[E1::NV];
+    auto stats_phase = [&](bf16* raw_out, float* st_out) {
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) {
+            const int row = r1 + k * E1::RPP;
+            if (raw_out) *(bf16x8*)(raw_out + (row0 + row) * E + v1 * 8) = xr[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)xr[k][j]; s[j] += f; ss[j] += f * f; }
+        }
+        group_store<E, M>(s, ss, wave, v1, lane, s_part);
+        __syncthreads();
+        group_finish<E, M, HW, 1>(tid, s_part, s_mr, a.eps, st_out, n0, a.N);
+        __syncthreads();
+    };
+    auto apply_phase = [&](const float* gamma, const float* beta, const unsigned char* mask, bf16* y_out) {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (v1 * 8 + j) / E1::CPG;
+            const float mean = s_mr[g * 2], rstd = s_mr[g * 2 + 1];
+            sc[j] = gamma[v1 * 8 + j] * rstd; sh[j] = beta[v1 * 8 + j] - mean * sc[j];
+        }
+        unsigned mk[E1::NV];
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) mk[k] = mask ? mask[((row0 + r1 + k * E1::RPP) * E + v1 * 8) >> 3] : 0xFFu;
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) {
+            const int row = r1 + k * E1::RPP;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = act_c<ACT>((float)xr[k][j] * sc[j] + sh[j]);
+                if (mask) z = (mk[k] >> j) & 1 ? z * a.mscale : 0.f;
+                o[j] = (bf16)z;
+            }
+            *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
+            if (y_out) *(bf16x8*)(y_out + (row0 + row) * E + v1 * 8) = o;
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) xr[k] = *(const bf16x8*)(s_e + (r1 + k * E1::RPP) * ES + v1 * 16);
+    stats_phase(rec ? a.raw_e : nullptr, rec ? a.st1 : nullptr);
+    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e, rec ? a.y_e : nullptr);
+    __syncthreads();
+
+    // ---- depthwise 3x3 from the LDS tile, four vectors at a time (accumulator registers)
+    {
+        constexpr int KB = 4;
+        float bd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bd[j] = s_p[P_BD + v1 * 8 + j];
+#pragma unroll 1
+        for (int k0 = 0; k0 < E1::NV; k0 += KB) {
+            float acc[KB][8];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][j] = bd[j];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                float w[8];
+                const f32x4 w0 = *(const f32x4*)(s_p + P_WD + tap * E + v1 * 8), w1 = *(const f32x4*)(s_p + P_WD + tap * E + v1 * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { w[j] = w0[j]; w[4 + j] = w1[j]; }
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const int row = r1 + (k0 + k) * E1::RPP;
+                    const int py = row / W, px = row % W;
+                    const int ny = py + dy, nx = px + dx;
+                    if (ny >= 0 && ny < W && nx >= 0 && nx < W) {
+                        const bf16x8 nv = *(const bf16x8*)(s_e + (row + dy * W + dx) * ES + v1 * 16);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[k][j] += (float)nv[j] * w[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[k][j];
+                // xr[] is indexed at run time here (k0 is a loop counter): select by compile-time comparison to stay in registers
+#pragma unroll
+                for (int q = 0; q < E1::NV; ++q)
+                    if (q == k0 + k) xr[q] = o;
+            }
+        }
+    }
+    bf16x8 bf2[E / 16];                            // projection weights of this lane's output channel (one N tile)
+#pragma unroll
+    for (int ks = 0; ks < E / 16; ++ks) bf2[ks] = *(const bf16x8*)(a.wp + (long long)(lane & 31) * E + ks * 16 + (lane >> 5) * 8);
+    stats_phase(rec ? a.raw_d : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
+    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e ? a.m_d : nullptr, rec ? a.y_d : nullptr);
+    __syncthreads();
+
+    // ---- project: all of this wave's tiles stay in accumulators until every wave has read the expanded tile
+    {
+        f32x16 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const char* ap = s_e + ((wave + NWV * i) * 32 + (lane & 31)) * ES + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < E / 16; ++ks) {
+                const bf16x8 av = *(const bf16x8*)(ap + ks * 32);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf2[ks], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        const float b = s_p[P_BP + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wave + NWV * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_e + row * XS + (lane & 31) * 2) = (bf16)(acc[i][r] + b);
+            }
+    }
+    __syncthreads();
+
+    // ---- last GroupNorm (no activation) + residual
+    {
+        const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
+        bf16x8 xo[E3::NV];
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const int row = r3 + k * E3::RPP;
+            xo[k] = *(const bf16x8*)(s_e + row * XS + v3 * 16);
+            if (rec) *(bf16x8*)(a.raw_o + (row0 + row) * C + v3 * 8) = xo[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
+        }
+        group_store<C, M>(s, ss, wave, v3, lane, s_part);
+        bf16x8 rx[E3::NV];
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) rx[k] = *(const bf16x8*)(a.x + (row0 + r3 + k * E3::RPP) * C + v3 * 8);
+        __syncthreads();
+        group_finish<C, M, HW, 1>(tid, s_part, s_mr, a.eps, rec ? a.st3 : nullptr, n0, a.N);
+        __syncthreads();
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (v3 * 8 + j) / E3::CPG;
+            const float mean = s_mr[g * 2], rstd = s_mr[g * 2 + 1];
+            sc[j] = s_p[P_G3 + v3 * 8 + j] * rstd; sh[j] = s_p[P_B3 + v3 * 8 + j] - mean * sc[j];
+        }
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const int row = r3 + k * E3::RPP;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)xo[k][j] * sc[j] + sh[j] + (float)rx[k][j]);
+            *(bf16x8*)(a.y + (row0 + row) * C + v3 * 8) = o;
+        }
+    }
+}
+
+template <int C, int W>
+__global__ __launch_bounds__(SIR_THREADS) void sir_fwd_big_kernel(const SirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    switch (a.act) {
+        case ACT_GELU: sir_fwd_big_body<C, W, ACT_GELU>(a, smem); break;
+        case ACT_SILU: sir_fwd_big_body<C, W, ACT_SILU>(a, smem); break;
+        default: sir_fwd_big_body<C, W, ACT_RELU>(a, smem); break;
+    }
+}
+
+template <int C, int W>
+static int sir_big_launch(const SirArgs& a, hipStream_t stream) {
+    constexpr int E = 2 * C, M = W * W;
+    constexpr int lds = M * (E * 2 + 16) + ((SIR_THREADS / 64) * 2 * SIR_G + 2 * SIR_G + 15 * E + 3 * C) * 4;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    auto k = sir_fwd_big_kernel<C, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            ddpm_set_error("sir_forward: cannot reserve %d bytes of LDS", lds);
+            return DDPM_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(a.N), dim3(SIR_THREADS), lds, stream, a);
+    return ddpm_check_launch("sir_forward");
+}
+
 template <int C, int W>
 static int sir_launch(const SirArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
@@ -402,7 +671,12 @@ extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int ac
     if (H != W || E != 2 * C || groups != SIR_G) return 0;
     if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU) return 0;
     return (C == 32 && W == 16) || (C == 64 && W == 8) || (C == 128 && W == 4) || (C == 256 && W == 2) ||
-           (C == 128 && W == 8) || (C == 256 && W == 4);
+           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32);
+}
+
+// 1 when the backward kernel (ddpm_sir_backward) also covers the shape; the largest images only have the fused forward
+extern "C" int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act) {
+    return ddpm_sir_supported(C, H, W, E, groups, act) && !(C == 32 && W == 32);
 }
 
 extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
@@ -425,6 +699,7 @@ extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
     a.raw_d = (bf16*)d->raw_d; a.y_d = (bf16*)d->y_d; a.st2 = d->st2;
     a.raw_o = (bf16*)d->raw_o; a.st3 = d->st3;
     a.N = d->N; a.act = d->act; a.eps = d->eps;
+    if (d->C == 32 && d->W == 32) return sir_big_launch<32, 32>(a, stream);
     if (d->C == 32 && d->W == 16) return sir_launch<32, 16>(a, stream);
     if (d->C == 64 && d->W == 8) return sir_launch<64, 8>(a, stream);
     if (d->C == 128 && d->W == 4) return sir_launch<128, 4>(a, stream);

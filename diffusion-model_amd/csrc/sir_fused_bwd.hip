@@ -449,7 +449,7 @@ extern "C" int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t strea
                      d->b2 && d->g3 && d->wpd && d->wed && d->wdf && d->dx && d->d_o && d->d_e && d->part1 && d->part2 && d->part3 &&
                      d->dwpart, "sir_backward: null pointer");
     DDPM_REQUIRE(d->N > 0, "sir_backward: N must be positive");
-    DDPM_REQUIRE(ddpm_sir_supported(d->C, d->H, d->W, d->E, d->groups, d->act),
+    DDPM_REQUIRE(ddpm_sir_backward_supported(d->C, d->H, d->W, d->E, d->groups, d->act),
                  "sir_backward: unsupported shape C=%d %dx%d E=%d groups=%d act=%d (use the unfused kernels)", d->C, d->H, d->W, d->E,
                  d->groups, d->act);
     DDPM_REQUIRE((d->m_in != nullptr) == (d->m_e != nullptr) && (d->m_e != nullptr) == (d->m_d != nullptr),

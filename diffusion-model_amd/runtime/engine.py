@@ -348,7 +348,13 @@ class UNetEngine:
                                         P[g3 + ".bias"], sp.groups, sp.act, masks=(m_in, m_e, m_d), mask_scale=mscale,
                                         record=tape is not None)
                 out = Var(y)
-                if tape is not None:
+                if tape is not None and not ops.sir_backward_supported(cc, hh, ww, ech, sp.groups, sp.act):
+                    # forward fused, backward through the per-unit kernels (they read what the fused forward saved)
+                    ev, dv = Var(sv["y_e"]), Var(sv["y_d"])
+                    tape.append(conv_bwd(ne, xin, None, None, m_in, sv["raw_e"], ev, sv["st1"], g1, sp.groups, sp.act, None, m_e))
+                    tape.append(dw_bwd(pre, ev, sv["raw_d"], dv, sv["st2"], m_d))
+                    tape.append(conv_bwd(npj, dv, None, None, None, sv["raw_o"], out, sv["st3"], g3, sp.groups, 0, xin, None))
+                elif tape is not None:
                     def bwd():
                         # data-gradient chain in one launch; the two pointwise weight gradients sum over the batch
                         # and stay separate GEMM launches

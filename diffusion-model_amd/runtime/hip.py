@@ -112,6 +112,7 @@ _PROTOS = {
     "ddpm_embed_forward": ([_vp, _vp], _i),
     "ddpm_embed_backward": ([_vp, _vp], _i),
     "ddpm_sir_supported": ([_i, _i, _i, _i, _i, _i], _i),
+    "ddpm_sir_backward_supported": ([_i, _i, _i, _i, _i, _i], _i),
     "ddpm_sir_forward": ([_vp, _vp], _i),
     "ddpm_sir_workgroups": ([_i, _i], _i),
     "ddpm_sir_backward": ([_vp, _vp], _i),

@@ -214,6 +214,10 @@ def sir_supported(c: int, h: int, w: int, e: int, groups: int, act: int) -> bool
     return bool(hip.lib().ddpm_sir_supported(c, h, w, e, groups, act))
 
 
+def sir_backward_supported(c: int, h: int, w: int, e: int, groups: int, act: int) -> bool:
+    return bool(hip.lib().ddpm_sir_backward_supported(c, h, w, e, groups, act))
+
+
 def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: Tensor, bd: Tensor, g2: Tensor, b2: Tensor,
                 wp: Tensor, bp: Tensor, g3: Tensor, b3: Tensor, groups: int, act: int, *, masks=(None, None, None),
                 mask_scale: float = 1.0, record: bool = False, eps: float = 1e-5):

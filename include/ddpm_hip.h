@@ -236,6 +236,7 @@ typedef struct ddpm_sir_desc {
     int32_t N, C, H, W, E, groups, act, pad;
 } ddpm_sir_desc;
 int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act);
+int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act);   /* shapes ddpm_sir_backward accepts */
 int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream);
 
 /* Data-gradient chain of the same block (backward of ddpm_sir_forward) in one launch.  dy: gradient w.r.t. the block
