@@ -674,9 +674,9 @@ extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int ac
            (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32);
 }
 
-// 1 when the backward kernel (ddpm_sir_backward) also covers the shape; the largest images only have the fused forward
+// 1 when the backward kernel (ddpm_sir_backward) also covers the shape
 extern "C" int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act) {
-    return ddpm_sir_supported(C, H, W, E, groups, act) && !(C == 32 && W == 32);
+    return ddpm_sir_supported(C, H, W, E, groups, act);
 }
 
 extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {

@@ -409,6 +409,347 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     }
 }
 
+
+// GroupNorm (+activation, +dropout) backward for a tile too large to keep an fp32 copy of the gradient in registers:
+// both passes read the incoming gradient from the LDS tile (bf16) and the raw tensor from global memory (the second
+// time an L2 hit) and evaluate the activation derivative again, like the unfused two-pass kernel; the result
+// replaces the incoming gradient in the tile (every thread owns its elements) and optionally goes to global memory.
+// Same slot protocol as norm_bwd.
+template <int CH, int M, int HW, int CS, int ACT>
+__device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* raw_g, const unsigned char* mask_g, long long elem0, float mscale,
+                                              const float* gamma, const float* beta, const float* s_mr, float* s_slot, float* s_grp,
+                                              float* part, bf16* out_g, long long n0, int tid) {
+    using T = Ew<CH, M>;
+    constexpr int NWV = SIR_THREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int vec = tid % T::VPR, r0 = tid / T::VPR;
+    float ga[8], be[8], mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int grp = (vec * 8 + j) / T::CPG;
+        ga[j] = gamma[vec * 8 + j]; be[j] = ACT != ACT_NONE ? beta[vec * 8 + j] : 0.f;
+        mean[j] = s_mr[grp * 2]; rstd[j] = s_mr[grp * 2 + 1];
+    }
+    // gradient w.r.t. the normalised (pre-activation) value and xhat, for 4 vectors of this thread
+    auto chunk = [&](int k0, float (&gg)[4][8], float (&xh)[4][8]) {
+        bf16x8 raw[4], gin[4];
+        unsigned mk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 * T::NV + k0 + k;
+            const long long e = (long long)row * CH + vec * 8;
+            raw[k] = *(const bf16x8*)(raw_g + e);
+            mk[k] = mask_g ? mask_g[(elem0 + e) >> 3] : 0xFFu;
+            gin[k] = *(const bf16x8*)(tile + row * TS + vec * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xh[k][j] = ((float)raw[k][j] - mean[j]) * rstd[j];
+                float v = (float)gin[k][j];
+                if constexpr (ACT != ACT_NONE) v *= act_d<ACT>(xh[k][j] * ga[j] + be[j]);
+                if (mask_g) v = (mk[k] >> j) & 1 ? v * mscale : 0.f;
+                gg[k][j] = v;
+            }
+    };
+    float a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+#pragma unroll 1
+    for (int k0 = 0; k0 < T::NV; k0 += 4) {
+        float gg[4][8], xh[4][8];
+        chunk(k0, gg, xh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a1[j] += gg[k][j]; a2[j] += gg[k][j] * xh[k][j]; }
+    }
+    col_store<CH, M, CS>(a1, wave, vec, lane, s_slot);
+    col_store<CH, M, CS>(a2, wave, vec, lane, s_slot + NWV * CS);
+    __syncthreads();
+    for (int t = tid; t < CH; t += SIR_THREADS) {
+        const float A1 = col_total<1, CS>(s_slot, 0, t), A2 = col_total<1, CS>(s_slot + NWV * CS, 0, t);
+        part[(n0 * 3 + 0) * CH + t] = A2;
+        part[(n0 * 3 + 1) * CH + t] = A1;
+        const float gm = gamma[t];
+        float u = A1 * gm, v = A2 * gm;
+#pragma unroll
+        for (int o = 1; o < T::CPG; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+        if ((t % T::CPG) == 0) {
+            const float inv = 1.0f / (float)(T::CPG * HW);
+            s_grp[(t / T::CPG) * 2] = u * inv;
+            s_grp[(t / T::CPG) * 2 + 1] = v * inv;
+        }
+    }
+    __syncthreads();
+    float db[8], S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int grp = (vec * 8 + j) / T::CPG;
+        db[j] = 0.f;
+        S1[j] = s_grp[grp * 2]; S2[j] = s_grp[grp * 2 + 1];
+    }
+#pragma unroll 1
+    for (int k0 = 0; k0 < T::NV; k0 += 4) {
+        float gg[4][8], xh[4][8];
+        chunk(k0, gg, xh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 * T::NV + k0 + k;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = rstd[j] * (ga[j] * gg[k][j] - (S1[j] + xh[k][j] * S2[j]));
+                db[j] += d;
+                o[j] = (bf16)d;
+            }
+            *(bf16x8*)(tile + row * TS + vec * 16) = o;
+            if (out_g) *(bf16x8*)(out_g + (long long)row * CH + vec * 8) = o;
+        }
+    }
+    col_store<CH, M, CS>(db, wave, vec, lane, s_slot + 2 * NWV * CS);
+}
+
+// Backward for images whose expanded tile fills the LDS on its own (32x32 pixels at C = 32): one [M][E] tile that is also
+// used, as an [M][C] view, for d_o before the projection data-gradient and for the expansion data-gradient at the end;
+// GEMM results that would overwrite their own operand stay in accumulators across a barrier.
+template <int C, int W, int ACT>
+__device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem) {
+    constexpr int E = 2 * C, HW = W * W, M = HW;
+    constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
+    constexpr int NWV = SIR_THREADS / 64, MT = M / 32, TPW = MT / NWV;
+    static_assert(C == 32 && MT % NWV == 0, "big variant: one input-channel tile, M tiles dealt evenly");
+    using E1 = Ew<E, M>;
+    using E3 = Ew<C, M>;
+    char* s_e = smem;
+    float* s_col = (float*)(smem + M * ES);        // [3][waves][E]
+    float* s_grp = s_col + 3 * NWV * E;            // [16][2]
+    float* s_mr = s_grp + 2 * SIR_G;               // [3][16][2]
+    float* s_p = s_mr + 3 * 2 * SIR_G;
+    constexpr int P_G1 = 0, P_B1 = E, P_G2 = 2 * E, P_B2 = 3 * E, P_WD = 4 * E, P_G3 = 13 * E;
+    float* s_dw = s_p + 13 * E + C;                // [10][E]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long n0 = blockIdx.x, row0 = n0 * HW;
+    const bool use_mask = a.m_e != nullptr;
+
+    for (int i = tid; i < 9 * E; i += SIR_THREADS) { s_dw[i] = 0.f; s_p[P_WD + i] = a.wdf[i]; }
+    for (int i = tid; i < E; i += SIR_THREADS) {
+        s_dw[9 * E + i] = 0.f;
+        s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i]; s_p[P_G2 + i] = a.g2[i]; s_p[P_B2 + i] = a.b2[i];
+    }
+    for (int i = tid; i < C; i += SIR_THREADS) s_p[P_G3 + i] = a.g3[i];
+    for (int i = tid; i < 3 * 2 * SIR_G; i += SIR_THREADS) {
+        const int which = i / (2 * SIR_G), rem = i % (2 * SIR_G);
+        const float* st = which == 0 ? a.st1 : which == 1 ? a.st2 : a.st3;
+        s_mr[i] = st[n0 * 2 * SIR_G + rem];
+    }
+    const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
+    const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
+    __syncthreads();
+
+    // ---- last GroupNorm backward: dy -> d_o (LDS [M][C] view + global)
+    {
+        bf16x8 rawo[E3::NV];
+        float g[E3::NV][8];
+        unsigned none[E3::NV];
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const long long e = (row0 + r3 * E3::NV + k) * C + v3 * 8;
+            const bf16x8 d = *(const bf16x8*)(a.dy + e);
+            rawo[k] = *(const bf16x8*)(a.raw_o + e);
+            none[k] = 0xFFu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[k][j] = (float)d[j];
+        }
+        norm_bwd<C, M, HW, 1, E, ACT_NONE>(rawo, g, none, false, 1.f, s_p + P_G3, s_p + P_G3, s_mr + 2 * 2 * SIR_G, s_col, s_grp, a.part3,
+                                          n0, a.N, tid);
+#pragma unroll
+        for (int k = 0; k < E3::NV; ++k) {
+            const int row = r3 * E3::NV + k;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)g[k][j];
+            *(bf16x8*)(s_e + row * XS + v3 * 16) = o;
+            *(bf16x8*)(a.d_o + (row0 + row) * C + v3 * 8) = o;
+        }
+    }
+    __syncthreads();
+    col2_flush<C, 1, E>(s_col, a.part3, n0, a.N, tid);
+
+    // ---- projection data-gradient: results wait in accumulators until every wave has read d_o, then fill the [M][E] tile
+    {
+        f32x16 acc[TPW][E / 32];
+        bf16x8 bfr[E / 32][C / 16];
+#pragma unroll
+        for (int nt = 0; nt < E / 32; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < C / 16; ++ks)
+                bfr[nt][ks] = *(const bf16x8*)(a.wpd + (long long)(nt * 32 + (lane & 31)) * C + ks * 16 + (lane >> 5) * 8);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const char* ap = s_e + ((wave + NWV * i) * 32 + (lane & 31)) * XS + (lane >> 5) * 16;
+            bf16x8 av[C / 16];
+#pragma unroll
+            for (int ks = 0; ks < C / 16; ++ks) av[ks] = *(const bf16x8*)(ap + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < E / 32; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][nt][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < C / 16; ++ks) acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks], bfr[nt][ks], acc[i][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int nt = 0; nt < E / 32; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave + NWV * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    *(bf16*)(s_e + row * ES + (nt * 32 + (lane & 31)) * 2) = (bf16)acc[i][nt][r];
+                }
+    }
+    __syncthreads();
+
+    // ---- second GroupNorm + activation + dropout backward -> dd (in place in the tile)
+    norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_d + row0 * E, use_mask ? a.m_d : nullptr, row0 * E, a.mscale, s_p + P_G2, s_p + P_B2,
+                                    s_mr + 2 * SIR_G, s_col, s_grp, a.part2, nullptr, n0, tid);
+    __syncthreads();
+    for (int c = tid; c < E; c += SIR_THREADS) s_dw[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
+
+    // ---- depthwise data-gradient and weight-gradient, four vectors at a time; the results replace dd in the tile once
+    //      every thread has finished reading its neighbours
+    bf16x8 dea[E1::NV];
+#pragma unroll
+    for (int k0 = 0; k0 < E1::NV; k0 += 4) {
+        float acc[4][8];
+        bf16x8 yev[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            yev[k] = *(const bf16x8*)(a.y_e + (row0 + r1 * E1::NV + k0 + k) * E + v1 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int t2 = 8 - tap;
+            const int dy = t2 / 3 - 1, dx = t2 % 3 - 1;
+            float w[8], wg[8];
+            const f32x4 w0 = *(const f32x4*)(s_p + P_WD + t2 * E + v1 * 8), w1 = *(const f32x4*)(s_p + P_WD + t2 * E + v1 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = w0[j]; w[4 + j] = w1[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wg[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r1 * E1::NV + k0 + k;
+                const int py = row / W, px = row % W;
+                const int ny = py + dy, nx = px + dx;
+                if (ny >= 0 && ny < W && nx >= 0 && nx < W) {
+                    const bf16x8 nv = *(const bf16x8*)(s_e + (row + dy * W + dx) * ES + v1 * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (float)nv[j];
+                        acc[k][j] += f * w[j];
+                        wg[j] += f * (float)yev[k][j];
+                    }
+                }
+            }
+            col_add<E, M, E>(wg, 0, v1, lane, s_dw + tap * E);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dea[k0 + k][j] = (bf16)acc[k][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E1::NV; ++k) *(bf16x8*)(s_e + (r1 * E1::NV + k) * ES + v1 * 16) = dea[k];
+
+    // ---- first GroupNorm + activation + dropout backward -> d_e (tile + global); own elements only, no barrier needed before
+    norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_e + row0 * E, use_mask ? a.m_e : nullptr, row0 * E, a.mscale, s_p + P_G1, s_p + P_B1, s_mr,
+                                    s_col, s_grp, a.part1, a.d_e + row0 * E, n0, tid);
+    __syncthreads();
+    col2_flush<E, 1, E>(s_col, a.part1, n0, a.N, tid);
+    for (int i = tid; i < 10 * E; i += SIR_THREADS) a.dwpart[n0 * 10 * E + i] = s_dw[i];
+
+    // ---- expansion data-gradient (accumulators across a barrier, then the [M][C] view of the tile)
+    {
+        f32x16 acc[TPW];
+        bf16x8 bfr[E / 16];
+#pragma unroll
+        for (int ks = 0; ks < E / 16; ++ks) bfr[ks] = *(const bf16x8*)(a.wed + (long long)(lane & 31) * E + ks * 16 + (lane >> 5) * 8);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const char* ap = s_e + ((wave + NWV * i) * 32 + (lane & 31)) * ES + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < E / 16; ++ks) {
+                const bf16x8 av = *(const bf16x8*)(ap + ks * 32);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bfr[ks], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wave + NWV * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_e + row * XS + (lane & 31) * 2) = (bf16)acc[i][r];
+            }
+    }
+    __syncthreads();
+
+    // ---- dropout of the block input and the residual branch
+#pragma unroll
+    for (int k = 0; k < E3::NV; ++k) {
+        const int row = r3 * E3::NV + k;
+        const long long e = (row0 + row) * C + v3 * 8;
+        const bf16x8 t = *(const bf16x8*)(s_e + row * XS + v3 * 16);
+        const bf16x8 dyv = *(const bf16x8*)(a.dy + e);
+        const unsigned m = a.m_in ? a.m_in[e >> 3] : 0xFFu;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = (float)t[j];
+            if (a.m_in) d = (m >> j) & 1 ? (float)(bf16)(d * a.mscale) : 0.f;
+            o[j] = (bf16)(d + (float)dyv[j]);
+        }
+        *(bf16x8*)(a.dx + e) = o;
+    }
+}
+
+template <int C, int W>
+__global__ __launch_bounds__(SIR_THREADS) void sir_bwd_big_kernel(const SirBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    switch (a.act) {
+        case ACT_GELU: sir_bwd_big_body<C, W, ACT_GELU>(a, smem); break;
+        case ACT_SILU: sir_bwd_big_body<C, W, ACT_SILU>(a, smem); break;
+        default: sir_bwd_big_body<C, W, ACT_RELU>(a, smem); break;
+    }
+}
+
+template <int C, int W>
+static int sir_bwd_big_launch(const SirBwdArgs& a, hipStream_t stream) {
+    constexpr int E = 2 * C, M = W * W;
+    constexpr int lds = M * (E * 2 + 16) + (3 * (SIR_THREADS / 64) * E + 2 * SIR_G + 3 * 2 * SIR_G + 13 * E + C + 10 * E) * 4;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    auto k = sir_bwd_big_kernel<C, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            ddpm_set_error("sir_backward: cannot reserve %d bytes of LDS", lds);
+            return DDPM_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(a.N), dim3(SIR_THREADS), lds, stream, a);
+    return ddpm_check_launch("sir_backward");
+}
+
 template <int C, int W>
 __global__ __launch_bounds__(SIR_THREADS) void sir_bwd_kernel(const SirBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -463,6 +804,7 @@ extern "C" int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t strea
     a.dx = (bf16*)d->dx; a.d_o = (bf16*)d->d_o; a.d_e = (bf16*)d->d_e;
     a.part1 = d->part1; a.part2 = d->part2; a.part3 = d->part3; a.dwpart = d->dwpart;
     a.N = d->N; a.act = d->act;
+    if (d->C == 32 && d->W == 32) return sir_bwd_big_launch<32, 32>(a, stream);
     if (d->C == 32 && d->W == 16) return sir_bwd_launch<32, 16>(a, stream);
     if (d->C == 64 && d->W == 8) return sir_bwd_launch<64, 8>(a, stream);
     if (d->C == 128 && d->W == 4) return sir_bwd_launch<128, 4>(a, stream);
