@@ -246,7 +246,7 @@ def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: T
         nb = _nb(x, y, we, wp, wd) + sum(_nb(t) for t in sv.values()) + sum(_nb(m) for m in masks)
         return nb, 2.0 * n * h * w * (2 * c * e + 9 * e), f"{h}x{w} C{c} E{e}" + (" rec" if record else "")
 
-    _launch("sir_fwd_kernel", cost, lambda: hip.call("ddpm_sir_forward", C.byref(d), hip.stream()))
+    _launch("sir_fwd_big_kernel" if h * w > 256 else "sir_fwd_kernel", cost, lambda: hip.call("ddpm_sir_forward", C.byref(d), hip.stream()))
     return y, saved
 
 
@@ -278,7 +278,7 @@ def sir_backward(dy: Tensor, saved: dict, g1: Tensor, b1: Tensor, g2: Tensor, b2
         nb = _nb(dy, dx, d_o, d_e, wpd, wed, saved["raw_e"], saved["raw_d"], saved["raw_o"], saved["y_e"]) + sum(_nb(m) for m in masks)
         return nb, 2.0 * n * h * w * (2 * c * e + 18 * e), f"{h}x{w} C{c} E{e}"
 
-    _launch("sir_bwd_kernel", cost, lambda: hip.call("ddpm_sir_backward", C.byref(d), hip.stream()))
+    _launch("sir_bwd_big_kernel" if h * w > 256 else "sir_bwd_kernel", cost, lambda: hip.call("ddpm_sir_backward", C.byref(d), hip.stream()))
     return dx, d_o, d_e
 
 

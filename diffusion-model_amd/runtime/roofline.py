@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 
+SPIN_CYCLES = 60000
 HBM_PEAK_GBS = 8000.0          # HBM3E peak of one MI355X
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak
 
@@ -27,6 +28,10 @@ class _Probe:
     def launch(self, kernel: str, cost, fn):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
+        # keep the GPU busy for a few tens of microseconds first, so that both events and the launch are already queued
+        # when it gets to them: otherwise the interval also contains the host's launch latency (several microseconds
+        # per call from Python), which a captured graph replay does not pay
+        torch.cuda._sleep(SPIN_CYCLES)
         e0.record()
         fn()
         e1.record()
