@@ -140,10 +140,10 @@ class UNetEngine:
             sir(co, hh, ww); sir(co, hh, ww)
         return sizes
 
-    def _make_masks(self, n: int, h: int, w: int, device) -> List[Tensor]:
-        key = (n, h, w)
+    def _make_masks(self, key, sizes_fn: Callable[[], List[int]], device) -> List[Tensor]:
+        """One keep-bit buffer for all dropout sites of a pass (element counts from sizes_fn, cached under key)."""
         if key not in self._mask_offsets:
-            sizes = self._site_sizes(n, h, w)
+            sizes = sizes_fn()
             nbytes = [(s // 8 + 3) // 4 * 4 for s in sizes]
             offs = [0]
             for b in nbytes:
@@ -158,20 +158,11 @@ class UNetEngine:
                  hip.stream())
         return [buf[offs[i]:offs[i + 1]] for i in range(nsites)]
 
-    # ------------------------------------------------------------------------------------------ forward
-    def forward(self, params: Dict[str, Tensor], x: Tensor, t: Tensor, train: bool, record: bool,
-                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None):
-        """x: NCHW fp32 on the GPU, t: int64 [N].  Returns (out NCHW fp32, tape or None).
-        train enables dropout; record keeps what backward needs."""
+    def _open(self, params: Dict[str, Tensor], n: int, dev, rkey, train: bool, record: bool, masks, site_sizes, taps=None):
+        """Start a pass: returns a namespace of the fused-unit builders (conv_unit, dw_unit, sir, embed, ...) bound to this
+        pass's tape, dropout masks and partial-sum workspace.  rkey identifies the program + shape (workspace layout cache);
+        site_sizes() lists the element counts of the dropout sites in call order."""
         sp = self.spec
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == sp.img_channels
-        x = x.contiguous()
-        t = t.to(torch.long).contiguous()
-        n, c_img, h, w = x.shape
-        nst = len(sp.stages)
-        if h % (1 << nst) or w % (1 << nst):
-            raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
-        dev = x.device
         self.wc.refresh(params, dev, force=self.always_repack)
         if record:
             if self.grads is None or self.grads.flat.device != dev:
@@ -179,7 +170,7 @@ class UNetEngine:
         tape: Optional[List[Callable[[], None]]] = [] if record else None
         use_drop = train and sp.drop_p > 0.0
         if use_drop and masks is None:
-            masks = self._make_masks(n, h, w, dev)
+            masks = self._make_masks(rkey, site_sizes, dev)
         mscale = 1.0 / (1.0 - sp.drop_p) if use_drop else 1.0
         site = [0]
         P = params
@@ -191,7 +182,6 @@ class UNetEngine:
         part_entries: List[Tuple[int, int, int, int, int]] = []
         part_cursor = [0]
         part_ws: List[Optional[Tensor]] = [None]
-        rkey = (n, h, w)
 
         pending: List = []                            # deferred weight-gradient problems: (descriptor, cost, tensors kept alive)
         first_time: List[Tuple[Tensor, int]] = []     # (separately allocated piece, its offset) until the total is known
@@ -395,6 +385,48 @@ class UNetEngine:
                 tape.append(bwd)
             return out
 
+        late: List[Callable[[], None]] = []           # backward work deferred to the end of the pass (before the reduction)
+
+        def finish():
+            for fn in late:
+                fn()
+            if pending:
+                self._launch_wgrad_group(pending, dev)
+                pending.clear()
+            if not part_entries and rkey not in self._reduce_tables:
+                return                                   # nothing was reduced in two stages in this pass
+            if rkey not in self._reduce_tables:
+                tab = ops.reduce_table(part_entries, dev)
+                self._reduce_tables[rkey] = (tab, len(part_entries), max(e[4] for e in part_entries), part_cursor[0])
+                part_ws[0] = torch.empty(part_cursor[0], device=dev, dtype=torch.float32)
+                for piece, off in first_time:
+                    part_ws[0][off:off + piece.numel()].copy_(piece)
+            tab, ne, mw, _ = self._reduce_tables[rkey]
+            ops.reduce_rows(part_ws[0], G.flat, tab, ne, mw)
+
+        from types import SimpleNamespace
+        return SimpleNamespace(P=P, G=G, wc=wc, tape=tape, conv_unit=conv_unit, conv_bwd=conv_bwd, dw_unit=dw_unit, sir=sir, embed=embed,
+                               wgrad=wgrad, part_alloc=part_alloc, part_entries=part_entries, gn_partials=gn_partials, tap=tap, late=late,
+                               finish=finish, mscale=mscale)
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, params: Dict[str, Tensor], x: Tensor, t: Tensor, train: bool, record: bool,
+                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None):
+        """x: NCHW fp32 on the GPU, t: int64 [N].  Returns (out NCHW fp32, tape or None).
+        train enables dropout; record keeps what backward needs."""
+        sp = self.spec
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == sp.img_channels
+        x = x.contiguous()
+        t = t.to(torch.long).contiguous()
+        n, c_img, h, w = x.shape
+        nst = len(sp.stages)
+        if h % (1 << nst) or w % (1 << nst):
+            raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
+        dev = x.device
+        c_ = self._open(params, n, dev, (n, h, w), train, record, masks, lambda: self._site_sizes(n, h, w), taps)
+        P, G, wc, tape, late = c_.P, c_.G, c_.wc, c_.tape, c_.late
+        conv_unit, sir, embed, wgrad, part_alloc, part_entries, tap, finish = (c_.conv_unit, c_.sir, c_.embed, c_.wgrad, c_.part_alloc,
+                                                                               c_.part_entries, c_.tap, c_.finish)
         # ---- the network ------------------------------------------------------------------------
         xin = torch.empty(n, h, w, 16, device=dev, dtype=BF16)
         hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(xin), n, c_img, h * w, 16, hip.stream())
@@ -408,7 +440,6 @@ class UNetEngine:
         enames = [f"{e}t_embeddings.{i}." for i in range(nst)] + [f"{d}t_embeddings.{i}." for i in range(nst)]
         ewidths = [P[q + "layers.2.bias"].shape[0] for q in enames]
         temb_vars: Dict[str, Var] = {}
-        late: List[Callable[[], None]] = []
         if (self.fuse_embed and sp.t_dim == 32 and len(enames) <= hip.EMBED_MAX and all(32 <= c <= 512 and c % 32 == 0 for c in ewidths)
                 and all(P[q + "layers.0.bias"].shape[0] == 2 * c for q, c in zip(enames, ewidths))):
             outs, esaved = ops.embed_forward(sin, [wc.fwd[q + "layers.0"] for q in enames], [P[q + "layers.0.bias"] for q in enames],
@@ -474,22 +505,33 @@ class UNetEngine:
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
             tape.append(bwd_head)
 
-            def finish():
-                for fn in late:
-                    fn()
-                if pending:
-                    self._launch_wgrad_group(pending, dev)
-                    pending.clear()
-                if rkey not in self._reduce_tables:
-                    tab = ops.reduce_table(part_entries, dev)
-                    self._reduce_tables[rkey] = (tab, len(part_entries), max(e[4] for e in part_entries), part_cursor[0])
-                    part_ws[0] = torch.empty(part_cursor[0], device=dev, dtype=torch.float32)
-                    for piece, off in first_time:
-                        part_ws[0][off:off + piece.numel()].copy_(piece)
-                tab, ne, mw, _ = self._reduce_tables[rkey]
-                ops.reduce_rows(part_ws[0], G.flat, tab, ne, mw)
             return out, (tape, out_holder, finish)
         return out, None
+
+    # ------------------------------------------------------------------------------------------ single blocks
+    def run_program(self, params: Dict[str, Tensor], inputs: List[Tensor], needs_grad: List[bool], program, key, train: bool, record: bool,
+                    site_sizes: Callable[[], List[int]]):
+        """Run a block-level program (one of the reference's constituent blocks) built from the same fused units as the
+        network.  inputs: device tensors in kernel layout (NHWC bf16, or bf16 [N,1,1,D] for an embedding input).
+        program(units, input Vars) -> output Var.  Returns (output tensor, context for backward_program or None)."""
+        dev = inputs[0].device
+        c_ = self._open(params, inputs[0].shape[0], dev, key, train, record, None, site_sizes)
+        in_vars = [Var(t, need_grad=record and g) for t, g in zip(inputs, needs_grad)]
+        out = program(c_, in_vars)
+        if not record:
+            return out.v, None
+        return out.v, (c_.tape, out, c_.finish, in_vars)
+
+    def backward_program(self, ctx, dout: Tensor):
+        """-> (gradients of the inputs (None where not needed), {parameter name: fp32 gradient in torch layout})"""
+        tape, out, finish, in_vars = ctx
+        self.grads.zero()
+        out.g = dout
+        for fn in reversed(tape):
+            fn()
+        finish()
+        tape.clear()
+        return [v.g for v in in_vars], self.grads.unpack()
 
     def _launch_wgrad_group(self, pending, dev) -> None:
         """All deferred dense weight gradients in at most five launches.  The problem tables are built on the host,

@@ -136,7 +136,7 @@ def test_train_mode_dropout_matches_oracle_with_exported_masks(dev):
     noise = hash_normal((n, 3, h, h), 22)
     s = O.make_schedule(120, 0.25)
     eng = m.model._get_engine()
-    masks = eng._make_masks(n, h, h, dev)
+    masks = eng._make_masks((n, h, h), lambda: eng._site_sizes(n, h, h), dev)
     sizes = eng._site_sizes(n, h, h)
     assert len(masks) == O.count_dropout_sites(cfg) == 60
     x_t = m.q(x0.to(dev), t.to(dev), noise=noise.to(dev))
