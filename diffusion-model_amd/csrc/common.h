@@ -138,3 +138,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Column sums across a workgroup: thread tid owns 8 per-channel values of vector column (tid % vps), vps a power of two
+// <= 8; on return every thread holds the sum over all threads of its column.  s_red: LDS, (THREADS/64)*64 floats (>= 128).
+template <int THREADS>
+__device__ __forceinline__ void block_reduce_cols(float (&v)[8], int vps, float* s_red /* [THREADS/64][64] */, int tid) {
+    // sum v[] over all threads with the same (tid % vps); result valid in every thread afterwards.
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = v[j];
+        for (int o = 32; o >= vps; o >>= 1) a += __shfl_xor(a, o, 64);
+        v[j] = a;
+    }
+    if constexpr (THREADS > 64) {
+        const int wave = tid >> 6, lane = tid & 63;
+        __syncthreads();
+        if (lane < vps) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_red[wave * 64 + lane * 8 + j] = v[j];
+        }
+        __syncthreads();
+        const int cv = lane % vps;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) a += s_red[w * 64 + cv * 8 + j];
+            v[j] = a;
+        }
+    }
+}

@@ -30,34 +30,6 @@ struct GnArgs {
     float eps;
 };
 
-template <int THREADS>
-__device__ __forceinline__ void block_reduce_cols(float (&v)[8], int vps, float* s_red /* [THREADS/64][64] */, int tid) {
-    // sum v[] over all threads with the same (tid % vps); result valid in every thread afterwards.
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float a = v[j];
-        for (int o = 32; o >= vps; o >>= 1) a += __shfl_xor(a, o, 64);
-        v[j] = a;
-    }
-    if constexpr (THREADS > 64) {
-        const int wave = tid >> 6, lane = tid & 63;
-        __syncthreads();
-        if (lane < vps) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s_red[wave * 64 + lane * 8 + j] = v[j];
-        }
-        __syncthreads();
-        const int cv = lane % vps;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < THREADS / 64; ++w) a += s_red[w * 64 + cv * 8 + j];
-            v[j] = a;
-        }
-    }
-}
-
 // NV = vectors a thread keeps in registers when the whole slab fits (NV > 0): the slab is then read from memory
 // exactly once, with all of a thread's loads in flight together; NV = 0 is the two-pass fallback for huge slabs.
 // Small NV with many threads is preferred: these kernels are latency bound, and a workgroup per image leaves a

@@ -66,6 +66,18 @@ class EmbedBwdDesc(C.Structure):
                 ("dtemb", _vp8), ("raw0", _vp8), ("w1d", _vp8), ("dt16", _vp8), ("dz", _vp8), ("db1", _vp8), ("db0", _vp8)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("o", _vp), ("ldo", C.c_int32),
+                ("lse", _vp), ("dout", _vp), ("ldd", C.c_int32), ("dq", _vp), ("dk", _vp), ("dv", _vp), ("lddq", C.c_int32),
+                ("lddk", C.c_int32), ("lddv", C.c_int32), ("N", C.c_int32), ("S", C.c_int32), ("Sk", C.c_int32), ("heads", C.c_int32),
+                ("dh", C.c_int32), ("drop_p", _f), ("seed", _vp), ("stream_id", _u32)]
+
+
+class SampleNormDesc(C.Structure):
+    _fields_ = [("a", _vp), ("b", _vp), ("gamma", _vp), ("beta", _vp), ("y", _vp), ("stats", _vp), ("dy", _vp), ("du", _vp), ("da", _vp),
+                ("part", _vp), ("N", C.c_int32), ("S", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("eps", _f)]
+
+
 class ReduceEntry(C.Structure):
     _fields_ = [("src_off", _i64), ("dst_off", _i64), ("rows", C.c_int32), ("row_stride", C.c_int32), ("width", C.c_int32),
                 ("pad", C.c_int32)]
@@ -120,6 +132,10 @@ _PROTOS = {
     "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
     "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),
     "ddpm_spatial_sum": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "ddpm_attention_forward": ([_vp, _vp], _i),
+    "ddpm_attention_backward": ([_vp, _vp], _i),
+    "ddpm_sample_norm_forward": ([_vp, _vp], _i),
+    "ddpm_sample_norm_backward": ([_vp, _vp], _i),
     "ddpm_dropout_masks": ([_vp, _vp, _i, _i64, _f, _vp, _vp], _i),
 }
 

@@ -282,6 +282,69 @@ def sir_backward(dy: Tensor, saved: dict, g1: Tensor, b1: Tensor, g2: Tensor, b2
     return dx, d_o, d_e
 
 
+def _tok_ld(t: Tensor) -> int:
+    """row stride (elements) of a token tensor [N, S, ..., width] whose last dim is contiguous (a channel slice of a packed buffer)"""
+    assert t.dtype == BF16 and t.stride(-1) == 1
+    return t.stride(1)
+
+
+def attention_forward(q: Tensor, k: Tensor, v: Tensor, heads: int, *, drop_p: float = 0.0, seed: Optional[Tensor] = None,
+                      stream_id: int = 0, want_lse: bool = True):
+    """q: bf16 [N,S,1,C] (or a channel slice of a packed projection output), k, v: [N,Sk,1,C].  Returns (o [N,S,1,C], lse fp32
+    [N,heads,S] or None)."""
+    n, s, c = q.shape[0], q.shape[1], q.shape[-1]
+    sk = k.shape[1]
+    dh = c // heads
+    assert dh * heads == c and k.shape[-1] == c and v.shape[-1] == c and v.shape[1] == sk
+    o = torch.empty(n, s, 1, c, device=q.device, dtype=BF16)
+    lse = torch.empty(n, heads, s, device=q.device, dtype=torch.float32) if want_lse else None
+    d = hip.AttnDesc(q=hip.ptr(q), k=hip.ptr(k), v=hip.ptr(v), ldq=_tok_ld(q), ldk=_tok_ld(k), ldv=_tok_ld(v), o=hip.ptr(o), ldo=c,
+                     lse=hip.ptr(lse), N=n, S=s, Sk=sk, heads=heads, dh=dh, drop_p=drop_p, seed=hip.ptr(seed), stream_id=stream_id)
+    _launch("attn_fwd_kernel", lambda: (2 * (2 * n * s * c + 2 * n * sk * c) + _nb(lse), 4.0 * n * s * sk * c, f"S{s} Sk{sk} h{heads} d{dh}"),
+            lambda: hip.call("ddpm_attention_forward", C.byref(d), hip.stream()))
+    return o, lse
+
+
+def attention_backward(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, dout: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
+                       heads: int, *, drop_p: float = 0.0, seed: Optional[Tensor] = None, stream_id: int = 0) -> None:
+    """Gradients of attention_forward into dq / dk / dv (token tensors or channel slices of one packed buffer)."""
+    n, s, c = q.shape[0], q.shape[1], q.shape[-1]
+    sk = k.shape[1]
+    d = hip.AttnDesc(q=hip.ptr(q), k=hip.ptr(k), v=hip.ptr(v), ldq=_tok_ld(q), ldk=_tok_ld(k), ldv=_tok_ld(v), o=hip.ptr(o), ldo=_tok_ld(o),
+                     lse=hip.ptr(lse), dout=hip.ptr(dout), ldd=_tok_ld(dout), dq=hip.ptr(dq), dk=hip.ptr(dk), dv=hip.ptr(dv),
+                     lddq=_tok_ld(dq), lddk=_tok_ld(dk), lddv=_tok_ld(dv), N=n, S=s, Sk=sk, heads=heads, dh=c // heads, drop_p=drop_p,
+                     seed=hip.ptr(seed), stream_id=stream_id)
+    _launch("attn_bwd_kernel", lambda: (2 * (4 * n * s * c + 4 * n * sk * c) + _nb(lse), 10.0 * n * s * sk * c, f"S{s} Sk{sk} h{heads} d{c // heads}"),
+            lambda: hip.call("ddpm_attention_backward", C.byref(d), hip.stream()))
+
+
+def sample_norm_forward(a: Tensor, b: Optional[Tensor], act: int, gamma: Tensor, beta: Tensor, eps: float = 1e-5):
+    """y = GroupNorm(1, C)(act(a) + b) over each sample of bf16 [N,S,1,C].  Returns (y, stats fp32 [N,2])."""
+    n, s, c = a.shape[0], a.numel() // (a.shape[0] * a.shape[-1]), a.shape[-1]
+    assert a.dtype == BF16 and a.is_contiguous() and (b is None or (b.shape == a.shape and b.is_contiguous()))
+    y = torch.empty_like(a)
+    stats = torch.empty(n, 2, device=a.device, dtype=torch.float32)
+    d = hip.SampleNormDesc(a=hip.ptr(a), b=hip.ptr(b), gamma=hip.ptr(gamma), beta=hip.ptr(beta), y=hip.ptr(y), stats=hip.ptr(stats),
+                           N=n, S=s, C=c, act=act, eps=eps)
+    _launch("sample_norm_fwd_kernel", lambda: (_nb(a, b, y, gamma, beta, stats), 0.0, f"S{s} C{c} a{act}"),
+            lambda: hip.call("ddpm_sample_norm_forward", C.byref(d), hip.stream()))
+    return y, stats
+
+
+def sample_norm_backward(a: Tensor, b: Optional[Tensor], dy: Tensor, act: int, gamma: Tensor, stats: Tensor, part: Tensor, eps: float = 1e-5):
+    """Returns (du, da): gradients w.r.t. (act(a) + b) and w.r.t. a (the same tensor when act is the identity).
+    part: fp32 [N][3][C] receives d gamma, d beta and the column sums of da per sample."""
+    n, s, c = a.shape[0], a.numel() // (a.shape[0] * a.shape[-1]), a.shape[-1]
+    assert dy.shape == a.shape and dy.dtype == BF16 and dy.is_contiguous() and part.numel() == n * 3 * c
+    du = torch.empty_like(a)
+    da = torch.empty_like(a) if act else None
+    d = hip.SampleNormDesc(a=hip.ptr(a), b=hip.ptr(b), gamma=hip.ptr(gamma), beta=None, y=None, stats=hip.ptr(stats), dy=hip.ptr(dy),
+                           du=hip.ptr(du), da=hip.ptr(da), part=hip.ptr(part), N=n, S=s, C=c, act=act, eps=eps)
+    _launch("sample_norm_bwd_kernel", lambda: (_nb(a, b, dy, du, da, gamma, stats, part), 0.0, f"S{s} C{c} a{act}"),
+            lambda: hip.call("ddpm_sample_norm_backward", C.byref(d), hip.stream()))
+    return du, (da if act else du)
+
+
 def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
     """x: NHWC bf16; w9c: fp32 [9][C] tap-major."""
     n, h, w, c = x.shape

@@ -293,6 +293,52 @@ typedef struct ddpm_embed_bwd_desc {
 } ddpm_embed_bwd_desc;
 int ddpm_embed_backward(const ddpm_embed_bwd_desc* d, ddpm_stream_t stream);
 
+/* ---- attention core and per-sample norm of ConditionalModule (attention.hip) -------------------------------------
+ * nn.MultiheadAttention's scaled-dot-product core (constituent_blocks.py:357-368,426: 8 heads, batch_first, dropout on
+ * the attention probabilities): o = dropout(softmax(q k^T / sqrt(dh))) v per (sample, head).  The in/out projections
+ * are 1x1 convolutions (ddpm_conv_forward).  Element (n, token, head, d) of q is q[(n*S + token)*ldq + head*dh + d]
+ * (bf16), likewise k, v (Sk tokens), o, and the gradients; a packed [N][S][3C] projection output is passed as three
+ * pointers with ld = 3C.  dh is 4 or a multiple of 8 up to 64; row strides are multiples of 8 (4 when dh = 4) and the
+ * base pointers aligned likewise.  lse: fp32 [N][heads][S], written by forward when not NULL (base-2 log-sum-exp of the
+ * scaled scores) and read by backward.  drop_p > 0 draws the keep mask from Philox keyed by (*seed, stream_id); backward
+ * must be given the same seed value and stream_id.  The keep probability is rounded to a multiple of 1/256. */
+typedef struct ddpm_attn_desc {
+    const void* q; const void* k; const void* v;
+    int32_t ldq, ldk, ldv;
+    void* o;                   /* forward: output; backward: the forward output (input) */
+    int32_t ldo;
+    float* lse;
+    const void* dout;          /* backward: gradient w.r.t. o, row stride ldd */
+    int32_t ldd;
+    void* dq; void* dk; void* dv;
+    int32_t lddq, lddk, lddv;
+    int32_t N, S, Sk, heads, dh;
+    float drop_p;
+    const uint64_t* seed;
+    uint32_t stream_id;
+} ddpm_attn_desc;
+int ddpm_attention_forward(const ddpm_attn_desc* d, ddpm_stream_t stream);
+int ddpm_attention_backward(const ddpm_attn_desc* d, ddpm_stream_t stream);
+
+/* y = GroupNorm(num_groups=1, C)(act(a) + b) * gamma + beta over all S*C elements of each sample
+ * (constituent_blocks.py:425-428: a = attention output projection, b = module input, act = identity; :431-434: a = Linear
+ * output, b = previous norm output, act = the block activation).  a, b, y: bf16 [N][S][C]; b may be NULL.
+ * stats: fp32 [N][2] (mean, rstd).  Backward: du = gradient w.r.t. (act(a) + b) (= gradient of b), da = du * act'(a)
+ * (may be NULL when act is DDPM_ACT_NONE), part fp32 [N][3][C] = per-sample d gamma, d beta and column sums of da (the bias
+ * gradient of the Linear that produced a), every element written once.  C = 8 x a power of two, at most 512. */
+typedef struct ddpm_sample_norm_desc {
+    const void* a; const void* b;
+    const float* gamma; const float* beta;
+    void* y;
+    float* stats;
+    const void* dy; void* du; void* da;
+    float* part;
+    int32_t N, S, C, act;
+    float eps;
+} ddpm_sample_norm_desc;
+int ddpm_sample_norm_forward(const ddpm_sample_norm_desc* d, ddpm_stream_t stream);
+int ddpm_sample_norm_backward(const ddpm_sample_norm_desc* d, ddpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
