@@ -316,8 +316,7 @@ extern "C" int ddpm_bump_seed(uint64_t* seed_, ddpm_stream_t stream_) {
 // Column sums of an NHWC bf16 matrix [rows][cs] -> fp32 [C] (+=): the bias gradient of a convolution whose
 // output gradient is not produced by a GroupNorm backward (the image head, the time-embedding MLPs).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, long long rows, int C, int cs,
-                                                      int rows_per_block) {
-    const int cvs = cs / 8;
+                                                      int rows_per_block, int cvs) {
     const int cv = threadIdx.x % cvs, prow = threadIdx.x / cvs, pstep = 256 / cvs;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
     float s[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
-    if (prow < pstep) {
+    if (prow < pstep && cv * 8 < C) {
         for (long long r = r0 + prow; r < r1; r += pstep) {
             const bf16x8 v = *(const bf16x8*)(x + r * cs + cv * 8);
 #pragma unroll
@@ -346,14 +345,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 extern "C" int ddpm_colsum(const void* x, float* out, int64_t rows, int C, int cs, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DDPM_REQUIRE(x && out && rows > 0 && C > 0 && cs >= C && cs % 8 == 0, "colsum: bad arguments");
-    const int cvs = cs / 8;
-    DDPM_REQUIRE(cvs <= 64 && (cvs & (cvs - 1)) == 0, "colsum: channel stride %d must be 8 * a power of two <= 512", cs);
+    // vector columns per row handled by one pass: the power of two covering C (the first C channels of each row; the row
+    // stride cs is free, so a channel range of a wider packed tensor can be summed by offsetting x)
+    int cvs = 1;
+    while (cvs * 8 < C) cvs <<= 1;
+    DDPM_REQUIRE(cvs <= 64 && C % 8 == 0 || cvs * 8 <= cs, "colsum: C = %d must be at most 512 (and a multiple of 8 unless the row is padded)", C);
+    DDPM_REQUIRE(cvs <= 64, "colsum: C = %d must be at most 512", C);
     long long blocks = (rows * cvs + 256 * 16 - 1) / (256 * 16);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const int rpb = (int)((rows + blocks - 1) / blocks);
     blocks = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, out, (long long)rows, C, cs, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, out, (long long)rows, C, cs, rpb, cvs);
     return ddpm_check_launch("colsum");
 }
 

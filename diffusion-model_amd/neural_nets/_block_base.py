@@ -95,7 +95,9 @@ class BlockModule(nn.Module):
         names = []
         for name, shape, rule in table:
             t = torch.empty(shape, device=device, dtype=torch.float32)
-            if rule == W_INIT:
+            if callable(rule):
+                rule(t)
+            elif rule == W_INIT:
                 init_w(t)
             elif rule == ONES:
                 nn.init.ones_(t)

@@ -5,15 +5,20 @@
     UpBlock:    cat(input, encoder_output) -> [conv3x3 + GN + act] -> SIR -> [convT 2x2 s2 + GN + act] -> SIR -> SIR  (:165-193,227-243)
     EmbedBlock: Linear(D -> 2C) -> act -> Linear(2C -> C) -> (N, C, 1, 1)                                  (:308-328)
 
-The attention-based ConditionalModule (is_conditional=True) is not built; the reference's blocks never insert it either
-(the insertion is commented out there, :92-101)."""
+    ConditionalModule: depth x { MultiheadAttention(8 heads) -> GroupNorm(1,C)(. + in) -> Linear -> act -> GroupNorm(1,C)(. + prev) }  (:331-437)
+
+The reference's Down/Up blocks never insert the ConditionalModule (the insertion is commented out there, :92-101,194-203);
+BaseUNet's `attention_stages` keyword places it where that commented code would, as self-attention."""
 from __future__ import annotations
 
 import torch
 from torch import Tensor, nn
 
+import math
+
 from ...runtime import hip
-from .._block_base import (BF16, LINEAR_BIAS_DEFAULT, ONES, W_INIT, BlockModule, BlockSpec, check_activation, conv_entries, norm_entries,
+from ...runtime.engine import attention_convs
+from .._block_base import (ZEROS, BF16, LINEAR_BIAS_DEFAULT, ONES, W_INIT, BlockModule, BlockSpec, check_activation, conv_entries, norm_entries,
                            sir_entries)
 
 
@@ -89,6 +94,81 @@ class UpBlock(BlockModule):
 
     def forward(self, input: Tensor, encoder_output: Tensor, *args, **kwargs) -> Tensor:
         return self._run(input, encoder_output)
+
+
+def _linear_default(fan_in: int):
+    """nn.Linear's default initialisation of weight and bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))"""
+    bound = 1.0 / math.sqrt(fan_in)
+    return lambda t: nn.init.uniform_(t, -bound, bound)
+
+
+def conditional_entries(pre: str, c: int, depth: int, kdim: int):
+    """Parameters of a ConditionalModule in the reference's registration order (constituent_blocks.py:357-399; inside
+    nn.MultiheadAttention: in_proj_weight or q/k/v_proj_weight, in_proj_bias, out_proj) with torch's default initialisers
+    (xavier_uniform for the input projections, zero attention biases, nn.Linear defaults elsewhere)."""
+    out = []
+    for i in range(depth):
+        m = f"{pre}mhas.{i}."
+        if kdim == c:
+            out.append((m + "in_proj_weight", (3 * c, c), nn.init.xavier_uniform_))
+        else:
+            out += [(m + "q_proj_weight", (c, c), nn.init.xavier_uniform_), (m + "k_proj_weight", (c, kdim), nn.init.xavier_uniform_),
+                    (m + "v_proj_weight", (c, kdim), nn.init.xavier_uniform_)]
+        out += [(m + "in_proj_bias", (3 * c,), ZEROS), (m + "out_proj.weight", (c, c), _linear_default(c)), (m + "out_proj.bias", (c,), ZEROS)]
+    for i in range(depth):
+        out += norm_entries(f"{pre}mha_norms.{i}", c)
+    for i in range(depth):
+        out += [(f"{pre}linears.{i}.weight", (c, c), _linear_default(c)), (f"{pre}linears.{i}.bias", (c,), _linear_default(c))]
+    for i in range(depth):
+        out += norm_entries(f"{pre}linear_norms.{i}", c)
+    return out
+
+
+class ConditionalModule(BlockModule):
+    """Drop-in for the reference ConditionalModule (constituent_blocks.py:331-437): forward(querry [N, S, C], condition
+    [N, Sk, kdim]) -> [N, S, C].  Passing the same tensor as both arguments is self-attention (one packed projection GEMM).
+    The reference passes `condition` as both key and value, so kdim must equal vdim."""
+
+    def __init__(self, in_channels: int, activation: str, depth, drop_p: float, kdim, vdim, device=None, dtype=None):
+        super().__init__()
+        check_activation(activation)
+        c, kdim, vdim = int(in_channels), int(kdim), int(vdim)
+        if kdim != vdim:
+            raise ValueError(f"condition is used as key and value, so kdim ({kdim}) must equal vdim ({vdim})")
+        if c % 32 or kdim % 16 or c // 8 not in (4, 8, 16, 24, 32, 40, 48, 56, 64):
+            raise ValueError(f"in_channels must be a multiple of 32 with a head width (in_channels / 8) the attention kernel supports, "
+                             f"kdim a multiple of 16; got {c}, {kdim}")
+        self.in_channels, self.kdim, self.depth = c, kdim, int(depth)
+        convs, aliases = {}, {}
+        attention_convs(convs, aliases, "", c, kdim, self.depth)
+        spec = BlockSpec(convs, [], 2, drop_p, activation, 4)
+        spec.aliases = aliases
+        self._build(conditional_entries("", c, self.depth, kdim), spec, "normal", device, dtype)
+
+    def _program(self, u, inputs):
+        cond = inputs[1] if len(inputs) > 1 else None
+        return u.attn_module("", inputs[0], cond, self.depth)
+
+    def _site_sizes(self, shapes):
+        return []
+
+    @staticmethod
+    def _to_kernel(x: Tensor) -> Tensor:
+        return x.to(BF16).contiguous().unsqueeze(2)
+
+    @staticmethod
+    def _from_kernel(o: Tensor) -> Tensor:
+        return o.squeeze(2).float()
+
+    _grad_to_kernel = _to_kernel
+    _grad_from_kernel = _from_kernel
+
+    def forward(self, querry: Tensor, condition: Tensor, **kwargs) -> Tensor:
+        if kwargs:
+            raise ValueError(f"attention keyword arguments are not supported by the fused kernel: {sorted(kwargs)}")
+        if condition is querry:
+            return self._run(querry)
+        return self._run(querry, condition)
 
 
 class SinusoidalPositionEmbedBlock(nn.Module):

@@ -61,14 +61,25 @@ def parameter_table(spec: UNetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
         out.append((pre + "layers.2.weight", (c, 2 * c), rule))
         out.append((pre + "layers.2.bias", (c,), ONES))
 
+    def attention(pre, c):
+        # torch's default initialisers; the table's ZEROS differs from the block modules' constant, so map it here
+        from .constituent_blocks import conditional_entries
+        from .._block_base import ZEROS as BLOCK_ZEROS, ONES as BLOCK_ONES
+        for name, shape, rule in conditional_entries(pre, c, spec.attn_depth, c):
+            out.append((name, shape, rule if callable(rule) else {BLOCK_ZEROS: ZEROS, BLOCK_ONES: ONES}[rule]))
+
     e = "encoder."
     conv(e + "stem_layers.0", st[0], spec.img_channels, 3)
     ins = [st[0]] + st[:-1]
     for i, (ci, co) in enumerate(zip(ins, st)):
         b = f"{e}layers.{i}.layers."
         conv(b + "0.0", co, ci, 3); norm(b + "0.1", co)
-        sir(b + "1.", co); sir(b + "2.", co)
-        conv(b + "3.0", co, co, 3); norm(b + "3.1", co)
+        k = 1
+        if i in spec.attn_stages:
+            attention(b + "1.", co)
+            k = 2
+        sir(f"{b}{k}.", co); sir(f"{b}{k + 1}.", co)
+        conv(f"{b}{k + 2}.0", co, co, 3); norm(f"{b}{k + 2}.1", co)
     for i, ci in enumerate(ins):
         embed(f"{e}t_embeddings.{i}.", ci, W_INIT)
     conv(e + "latent_layers.0", spec.latent_dim, st[-1], 3); norm(e + "latent_layers.1", spec.latent_dim)
@@ -80,14 +91,27 @@ def parameter_table(spec: UNetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
     for i, (ci, co) in enumerate(zip(rs, outs)):
         b = f"{d}layers.{i}.layers."
         conv(b + "0.0", ci, 2 * ci, 3); norm(b + "0.1", ci)
-        sir(b + "1.", ci)
-        out.append((b + "2.0.weight", (ci, co, 2, 2), W_INIT)); out.append((b + "2.0.bias", (co,), ONES)); norm(b + "2.1", co)
-        sir(b + "3.", co); sir(b + "4.", co)
+        k = 1
+        if len(st) - 1 - i in spec.attn_stages:
+            attention(b + "1.", ci)
+            k = 2
+        sir(f"{b}{k}.", ci)
+        out.append((f"{b}{k + 1}.0.weight", (ci, co, 2, 2), W_INIT)); out.append((f"{b}{k + 1}.0.bias", (co,), ONES)); norm(f"{b}{k + 1}.1", co)
+        sir(f"{b}{k + 2}.", co); sir(f"{b}{k + 3}.", co)
     for i, ci in enumerate(rs):
         embed(f"{d}t_embeddings.{i}.", ci, W_INIT_EMBED_DEC)
     conv(d + "out_layers.0", rs[-1], rs[-1], 3)
     conv(d + "out_layers.2", spec.img_channels, rs[-1], 3, bias_rule=ZEROS)
     return out
+
+
+def _int_list(v) -> List[int]:
+    """CLI passthrough keywords arrive as strings (experiments_setup/utils.py:40-50 of the reference): accept "2", "1,2", [1, 2]."""
+    if isinstance(v, str):
+        return [int(x) for x in v.replace("[", "").replace("]", "").split(",") if x.strip()]
+    if isinstance(v, int):
+        return [v]
+    return [int(x) for x in v]
 
 
 class _UNetFn(torch.autograd.Function):
@@ -119,7 +143,12 @@ class BaseUNet(nn.Module):
 
     Keyword arguments are the ones the reference forwards (DDPM.yaml + CLI extras, unknown ones are accepted and
     ignored, dm_utils.py:39-58 there).  `T` is NOT forwarded by the reference's DDPM wrapper, so the time
-    normaliser defaults to 100 exactly as it does there."""
+    normaliser defaults to 100 exactly as it does there.
+
+    Extension (no counterpart in the reference, whose `is_conditional` branches are commented out,
+    constituent_blocks.py:92-101,194-203): `attention_stages=[i, ...]` inserts a self-attention ConditionalModule
+    (condition = the layer's own input, kdim = vdim = C, `attention_depth` layers, default 1) at `layers[1]` of encoder
+    stage i's DownBlock and of the decoder UpBlock working at the same resolution - where that commented code would."""
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -129,7 +158,8 @@ class BaseUNet(nn.Module):
             img_channels=kwargs["img_channels"], stages_channels=kwargs["stages_channels"], latent_dim=kwargs["latent_dim"],
             expand_factor=kwargs.get("expand_factor", 4), drop_p=float(kwargs.get("drop_p", 0.1)),
             t_embed_dim=kwargs.get("t_embed_dim", 32), activation=act_name, base_groups_norm=kwargs["base_groups_norm"],
-            time_norm=float(kwargs.get("T", 100)))
+            time_norm=float(kwargs.get("T", 100)), attention_stages=_int_list(kwargs.get("attention_stages", ())),
+            attention_depth=int(kwargs.get("attention_depth", 1)))
         self.is_conditional = bool(kwargs.get("is_conditional", False))
         device, dtype = kwargs.get("device", None), kwargs.get("dtype", None)
         if dtype not in (None, torch.float32):
@@ -140,7 +170,9 @@ class BaseUNet(nn.Module):
         names = []
         for name, shape, rule in parameter_table(self.spec):
             t = torch.empty(shape, device=device, dtype=torch.float32)
-            if rule == W_INIT:
+            if callable(rule):
+                rule(t)
+            elif rule == W_INIT:
                 init_w(t)
             elif rule == W_INIT_EMBED_DEC:
                 init_dec_embed(t)

@@ -38,13 +38,43 @@ class Var:
         self.need_grad = need_grad
 
 
+def attention_convs(convs: Dict[str, int], aliases: Dict[str, Tuple[str, int, int]], pre: str, c: int, kdim: int, depth: int) -> None:
+    """Register the pointwise weights of a ConditionalModule (constituent_blocks.py:357-396) under `pre`.  With
+    kdim == C nn.MultiheadAttention keeps one packed in_proj_weight [3C][C]: the logical names in_proj (all rows, the
+    self-attention GEMM), in_proj_q and in_proj_kv (cross-attention: query rows / key+value rows) are row ranges of it.
+    Otherwise it keeps q_proj_weight [C][C], k_proj_weight and v_proj_weight [C][kdim]."""
+    for i in range(depth):
+        m = f"{pre}mhas.{i}."
+        if kdim == c:
+            for name, r0, rows in (("in_proj", 0, 3 * c), ("in_proj_q", 0, c), ("in_proj_kv", c, 2 * c)):
+                convs[m + name] = K11
+                aliases[m + name + ".weight"] = (m + "in_proj_weight", r0, rows)
+        else:
+            for name in ("q_proj", "k_proj", "v_proj"):
+                convs[m + name] = K11
+                aliases[m + name + ".weight"] = (m + name + "_weight", 0, c)
+        convs[m + "out_proj"] = K11
+        convs[f"{pre}linears.{i}"] = K11
+
+
+def _view_var(src: "Var", shape, tape) -> "Var":
+    """A Var whose tensor is src's viewed as `shape`; in backward its gradient is handed to src (same memory, reshaped)."""
+    out = Var(src.v.view(shape))
+
+    def bwd():
+        src.g = None if out.g is None else out.g.view(src.v.shape)
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
 class UNetSpec:
     """Static description of the denoiser: which parameters exist, their kinds and shapes.
     Mirrors the constructor keywords the reference forwards to BaseUNet (dm_utils.py:39-58)."""
 
     def __init__(self, img_channels: int, stages_channels: Sequence[int], latent_dim: int, expand_factor: int = 2,
                  drop_p: float = 0.1, t_embed_dim: int = 32, activation: str = "gelu", base_groups_norm: int = 4,
-                 time_norm: float = 100.0):
+                 time_norm: float = 100.0, attention_stages: Sequence[int] = (), attention_depth: int = 1):
         self.img_channels = int(img_channels)
         self.stages = [int(c) for c in stages_channels]
         self.latent_dim = int(latent_dim)
@@ -60,9 +90,18 @@ class UNetSpec:
                 raise ValueError(f"stage/latent channel counts must be multiples of 32 for the MFMA kernels, got {c}")
         if self.t_dim % 32:
             raise ValueError(f"t_embed_dim must be a multiple of 32, got {self.t_dim}")
+        # stages whose Down/Up blocks carry a self-attention ConditionalModule at layers[1] (where the reference's
+        # commented-out construction would insert it: constituent_blocks.py:92-101,194-203), and its depth
+        self.attn_stages = sorted(int(i) for i in attention_stages)
+        self.attn_depth = int(attention_depth)
+        self.attn_heads = 8
+        for i in self.attn_stages:
+            if not 0 <= i < len(self.stages):
+                raise ValueError(f"attention stage {i} out of range for {len(self.stages)} stages")
         # (name, kind) of every convolution weight, for packing
         self.convs: Dict[str, int] = {}
         self.dwconvs: List[str] = []
+        self.aliases: Dict[str, Tuple[str, int, int]] = {}
         self._enumerate()
 
     def _sir(self, pre: str):
@@ -77,9 +116,13 @@ class UNetSpec:
         for i in range(n):
             b = f"{e}layers.{i}.layers."
             self.convs[b + "0.0"] = K33S2
-            self._sir(b + "1.")
-            self._sir(b + "2.")
-            self.convs[b + "3.0"] = K33
+            k = 1
+            if i in self.attn_stages:
+                attention_convs(self.convs, self.aliases, b + "1.", self.stages[i], self.stages[i], self.attn_depth)
+                k = 2
+            self._sir(f"{b}{k}.")
+            self._sir(f"{b}{k + 1}.")
+            self.convs[f"{b}{k + 2}.0"] = K33
             self.convs[f"{e}t_embeddings.{i}.layers.0"] = K11
             self.convs[f"{e}t_embeddings.{i}.layers.2"] = K11
         self.convs[e + "latent_layers.0"] = K33
@@ -87,10 +130,14 @@ class UNetSpec:
         for i in range(n):
             b = f"{d}layers.{i}.layers."
             self.convs[b + "0.0"] = K33
-            self._sir(b + "1.")
-            self.convs[b + "2.0"] = KT22
-            self._sir(b + "3.")
-            self._sir(b + "4.")
+            k = 1
+            if n - 1 - i in self.attn_stages:
+                attention_convs(self.convs, self.aliases, b + "1.", self.stages[n - 1 - i], self.stages[n - 1 - i], self.attn_depth)
+                k = 2
+            self._sir(f"{b}{k}.")
+            self.convs[f"{b}{k + 1}.0"] = KT22
+            self._sir(f"{b}{k + 2}.")
+            self._sir(f"{b}{k + 3}.")
             self.convs[f"{d}t_embeddings.{i}.layers.0"] = K11
             self.convs[f"{d}t_embeddings.{i}.layers.2"] = K11
         self.convs[d + "out_layers.0"] = K33
@@ -102,7 +149,7 @@ class UNetEngine:
 
     def __init__(self, spec: UNetSpec):
         self.spec = spec
-        self.wc = WeightCache(spec.convs, spec.dwconvs)
+        self.wc = WeightCache(spec.convs, spec.dwconvs, getattr(spec, "aliases", None))
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
@@ -166,7 +213,7 @@ class UNetEngine:
         self.wc.refresh(params, dev, force=self.always_repack)
         if record:
             if self.grads is None or self.grads.flat.device != dev:
-                self.grads = GradStore(sp.convs, sp.dwconvs, params, dev)
+                self.grads = GradStore(sp.convs, sp.dwconvs, params, dev, getattr(sp, "aliases", None))
         tape: Optional[List[Callable[[], None]]] = [] if record else None
         use_drop = train and sp.drop_p > 0.0
         if use_drop and masks is None:
@@ -385,6 +432,110 @@ class UNetEngine:
                 tape.append(bwd)
             return out
 
+        attn_site = [0]
+
+        def attn_module(pre: str, z: Var, cond: Optional[Var], depth: int, heads: int = 8) -> Var:
+            """ConditionalModule.forward (constituent_blocks.py:402-437): depth x { multi-head attention of z over cond ->
+            GroupNorm(1, C)(. + z) -> Linear -> act -> GroupNorm(1, C)(. + previous) }.  z: tokens [N, S, 1, C] (an NHWC
+            activation viewed as tokens); cond: [N, Sk, 1, kdim], or None for self-attention (cond = the layer's own input).
+            Projections and the feed-forward are pointwise GEMMs on the convolution kernel, the attention core and the two
+            per-sample norms have their own kernels; attention-probability dropout is drawn in-kernel.
+            The reference passes the same `condition` to every layer (:423-426), so with cond = None layer 0 is true
+            self-attention (one packed q,k,v GEMM) and deeper layers attend over the module's input tokens."""
+            c = z.v.shape[-1]
+            s_q = z.v.numel() // (n * c)
+            shape_in = z.v.shape
+            cur = Var(z.v.view(n, s_q, 1, c), z.need_grad)
+            first = cur
+            if tape is not None:
+                def hand_back():                        # runs last in backward: the token view's gradient is the input's
+                    if first.g is not None:
+                        assert z.g is None
+                        z.g = first.g.view(shape_in)
+                tape.append(hand_back)
+            p_drop = sp.drop_p if use_drop else 0.0
+            if p_drop > 0.0 and self.seed is None:
+                self.seed = torch.randint(0, 2 ** 62, (1,), device=dev, dtype=torch.long)
+            for i in range(depth):
+                m, mn, lin, ln = f"{pre}mhas.{i}.", f"{pre}mha_norms.{i}", f"{pre}linears.{i}", f"{pre}linear_norms.{i}"
+                packed = (m + "in_proj_weight") in P
+                b_in = P[m + "in_proj_bias"]
+                gb_in = G[m + "in_proj_bias"] if tape is not None else None
+                sid = 0x1000 + attn_site[0]
+                attn_site[0] += 1
+                x_in = cur
+                cnd = cond if cond is not None else (None if i == 0 else first)
+                if cnd is None:
+                    if not packed:
+                        raise ValueError("self-attention needs kdim == vdim == in_channels (a packed in_proj_weight)")
+                    qkv = ops.conv_forward(K11, x_in.v, wc.fwd[m + "in_proj"], b_in, 3 * c)
+                    q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+                elif packed:
+                    q = ops.conv_forward(K11, x_in.v, wc.fwd[m + "in_proj_q"], b_in[:c], c)
+                    kv = ops.conv_forward(K11, cnd.v, wc.fwd[m + "in_proj_kv"], b_in[c:], 2 * c)
+                    k, v = kv[..., :c], kv[..., c:]
+                else:
+                    q = ops.conv_forward(K11, x_in.v, wc.fwd[m + "q_proj"], b_in[:c], c)
+                    k = ops.conv_forward(K11, cnd.v, wc.fwd[m + "k_proj"], b_in[c:2 * c], c)
+                    v = ops.conv_forward(K11, cnd.v, wc.fwd[m + "v_proj"], b_in[2 * c:], c)
+                o, lse = ops.attention_forward(q, k, v, heads, drop_p=p_drop, seed=self.seed, stream_id=sid, want_lse=tape is not None)
+                r_raw = ops.conv_forward(K11, o, wc.fwd[m + "out_proj"], P[m + "out_proj.bias"], c, res=x_in.v)
+                r, st1 = ops.sample_norm_forward(r_raw, None, 0, P[mn + ".weight"], P[mn + ".bias"])
+                h_raw = ops.conv_forward(K11, r, wc.fwd[lin], P[lin + ".bias"], c)
+                y, st2 = ops.sample_norm_forward(h_raw, r, sp.act, P[ln + ".weight"], P[ln + ".bias"])
+                out = Var(y)
+                if tape is not None:
+                    def bwd(m=m, mn=mn, lin=lin, ln=ln, packed=packed, cnd=cnd, gb_in=gb_in, sid=sid, x_in=x_in, q=q, k=k, v=v, o=o, lse=lse,
+                            r_raw=r_raw, r=r, st1=st1, h_raw=h_raw, st2=st2, out=out):
+                        du2, da2 = ops.sample_norm_backward(h_raw, r, out.g, sp.act, P[ln + ".weight"], st2, gn_partials(c, ln, lin))
+                        out.g = None
+                        wgrad(K11, r, da2, c, lin)
+                        dr = ops.conv_forward(K11, da2, wc.dgrad[lin], None, c, res=du2)
+                        du1, _ = ops.sample_norm_backward(r_raw, None, dr, 0, P[mn + ".weight"], st1, gn_partials(c, mn, m + "out_proj"))
+                        wgrad(K11, o, du1, c, m + "out_proj")
+                        d_o = ops.conv_forward(K11, du1, wc.dgrad[m + "out_proj"], None, c)
+                        kw = dict(drop_p=p_drop, seed=self.seed, stream_id=sid)
+                        sk = k.shape[1]
+                        if cnd is None:
+                            dqkv = torch.empty(n, s_q, 1, 3 * c, device=dev, dtype=BF16)
+                            ops.attention_backward(q, k, v, o, lse, d_o, dqkv[..., :c], dqkv[..., c:2 * c], dqkv[..., 2 * c:], heads, **kw)
+                            for j in range(3):
+                                ops.colsum(dqkv[..., j * c:(j + 1) * c], gb_in[j * c:(j + 1) * c], c)
+                            wgrad(K11, x_in.v, dqkv, 3 * c, m + "in_proj")
+                            if x_in.need_grad:
+                                gx = ops.conv_forward(K11, dqkv, wc.dgrad[m + "in_proj"], None, c, res=du1)
+                                if x_in.g is not None:          # deeper layers already left their key/value gradients here
+                                    gx, _ = ops.gn_act_forward(gx, None, None, 0, 0, res=x_in.g)
+                                x_in.g = gx
+                            return
+                        dq = torch.empty(n, s_q, 1, c, device=dev, dtype=BF16)
+                        if packed:
+                            dkv = torch.empty(n, sk, 1, 2 * c, device=dev, dtype=BF16)
+                            ops.attention_backward(q, k, v, o, lse, d_o, dq, dkv[..., :c], dkv[..., c:], heads, **kw)
+                            ops.colsum(dq, gb_in[:c], c)
+                            ops.colsum(dkv[..., :c], gb_in[c:2 * c], c)
+                            ops.colsum(dkv[..., c:], gb_in[2 * c:], c)
+                            wgrad(K11, x_in.v, dq, c, m + "in_proj_q")
+                            wgrad(K11, cnd.v, dkv, 2 * c, m + "in_proj_kv")
+                            if cnd.need_grad:
+                                cnd.g = ops.conv_forward(K11, dkv, wc.dgrad[m + "in_proj_kv"], None, cnd.v.shape[-1], res=cnd.g)
+                            qname = m + "in_proj_q"
+                        else:
+                            dk, dv = (torch.empty(n, sk, 1, c, device=dev, dtype=BF16) for _ in range(2))
+                            ops.attention_backward(q, k, v, o, lse, d_o, dq, dk, dv, heads, **kw)
+                            for t_, lo, nm in ((dq, 0, "q_proj"), (dk, c, "k_proj"), (dv, 2 * c, "v_proj")):
+                                ops.colsum(t_, gb_in[lo:lo + c], c)
+                                wgrad(K11, x_in.v if nm == "q_proj" else cnd.v, t_, c, m + nm)
+                            if cnd.need_grad:
+                                g_ = ops.conv_forward(K11, dk, wc.dgrad[m + "k_proj"], None, cnd.v.shape[-1], res=cnd.g)
+                                cnd.g = ops.conv_forward(K11, dv, wc.dgrad[m + "v_proj"], None, cnd.v.shape[-1], res=g_)
+                            qname = m + "q_proj"
+                        if x_in.need_grad:
+                            x_in.g = ops.conv_forward(K11, dq, wc.dgrad[qname], None, c, res=du1)
+                    tape.append(bwd)
+                cur = out
+            return Var(cur.v.view(shape_in)) if tape is None else _view_var(cur, shape_in, tape)
+
         late: List[Callable[[], None]] = []           # backward work deferred to the end of the pass (before the reduction)
 
         def finish():
@@ -406,6 +557,7 @@ class UNetEngine:
 
         from types import SimpleNamespace
         return SimpleNamespace(P=P, G=G, wc=wc, tape=tape, conv_unit=conv_unit, conv_bwd=conv_bwd, dw_unit=dw_unit, sir=sir, embed=embed,
+                               attn_module=attn_module,
                                wgrad=wgrad, part_alloc=part_alloc, part_entries=part_entries, gn_partials=gn_partials, tap=tap, late=late,
                                finish=finish, mscale=mscale)
 
@@ -471,9 +623,13 @@ class UNetEngine:
             b = f"{e}layers.{i}.layers."
             temb = temb_vars.get(f"{e}t_embeddings.{i}.") or embed(f"{e}t_embeddings.{i}.", sin_v)
             a = conv_unit(b + "0.0", z, in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
-            a = sir(b + "1.", a)
-            a = sir(b + "2.", a)
-            z = conv_unit(b + "3.0", a, norm=b + "3.1", groups=sp.groups, act=sp.act)
+            k = 1
+            if i in sp.attn_stages:
+                a = c_.attn_module(b + "1.", a, None, sp.attn_depth, sp.attn_heads)
+                k = 2
+            a = sir(f"{b}{k}.", a)
+            a = sir(f"{b}{k + 1}.", a)
+            z = conv_unit(f"{b}{k + 2}.0", a, norm=f"{b}{k + 2}.1", groups=sp.groups, act=sp.act)
             skips.append(z)
             tap(f"enc.stage{i}", z.v)
         z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
@@ -484,10 +640,14 @@ class UNetEngine:
             b = f"{d}layers.{i}.layers."
             temb = temb_vars.get(f"{d}t_embeddings.{i}.") or embed(f"{d}t_embeddings.{i}.", sin_v)
             a = conv_unit(b + "0.0", z, x1=skips[nst - 1 - i], in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
-            a = sir(b + "1.", a)
-            a = conv_unit(b + "2.0", a, norm=b + "2.1", groups=sp.groups, act=sp.act)
-            a = sir(b + "3.", a)
-            z = sir(b + "4.", a)
+            k = 1
+            if nst - 1 - i in sp.attn_stages:
+                a = c_.attn_module(b + "1.", a, None, sp.attn_depth, sp.attn_heads)
+                k = 2
+            a = sir(f"{b}{k}.", a)
+            a = conv_unit(f"{b}{k + 1}.0", a, norm=f"{b}{k + 1}.1", groups=sp.groups, act=sp.act)
+            a = sir(f"{b}{k + 2}.", a)
+            z = sir(f"{b}{k + 3}.", a)
             tap(f"dec.stage{i}", z.v)
         hfeat = conv_unit(d + "out_layers.0", z, act=sp.act)
         name = d + "out_layers.2"

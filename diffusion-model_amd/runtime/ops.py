@@ -385,9 +385,9 @@ def reduce_table(entries, device) -> Tensor:
 
 
 def colsum(x: Tensor, out: Tensor, c: int) -> None:
-    """out[c] += sum over rows of NHWC bf16 x (any leading dims, last dim = channel stride)."""
-    cs = x.shape[-1]
-    hip.call("ddpm_colsum", hip.ptr(x), hip.ptr(out), x.numel() // cs, c, cs, hip.stream())
+    """out[c] += sum over rows of NHWC bf16 x (any leading dims; x may be a channel slice of a wider packed tensor)."""
+    cs = x.stride(-2)
+    hip.call("ddpm_colsum", hip.ptr(x), hip.ptr(out), x.numel() // x.shape[-1], c, cs, hip.stream())
 
 
 def spatial_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:

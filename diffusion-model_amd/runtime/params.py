@@ -53,6 +53,15 @@ def _to_device(entries: List[hip.RemapEntry], device) -> Tuple[Tensor, Tensor, i
     return t, ct, len(chunks)
 
 
+def lookup(params: Dict[str, Tensor], aliases: Dict[str, Tuple[str, int, int]], key: str) -> Tensor:
+    """params[key], or - for a logical name that stands for a row range of a packed parameter (the q / k,v blocks of
+    nn.MultiheadAttention's in_proj_weight, or its q_proj_weight-style names) - that row range as a view."""
+    if key in params:
+        return params[key]
+    real, r0, rows = aliases[key]
+    return params[real][r0:r0 + rows]
+
+
 def conv_dims(kind: int, w: Tensor) -> Tuple[int, int, int]:
     """(Cout, Cin, taps) of a dense convolution / linear weight in torch layout."""
     if kind == KT22:
@@ -64,8 +73,8 @@ def conv_dims(kind: int, w: Tensor) -> Tuple[int, int, int]:
 class WeightCache:
     """Kernel-layout copies of all convolution weights, refreshed by ONE remap launch."""
 
-    def __init__(self, convs: Dict[str, int], dwconvs: List[str]):
-        self.convs, self.dwconvs = convs, dwconvs
+    def __init__(self, convs: Dict[str, int], dwconvs: List[str], aliases: Dict[str, Tuple[str, int, int]] = None):
+        self.convs, self.dwconvs, self.aliases = convs, dwconvs, aliases or {}
         self.fwd: Dict[str, Tensor] = {}
         self.dgrad: Dict[str, Tensor] = {}
         self.dw: Dict[str, Tensor] = {}
@@ -78,7 +87,7 @@ class WeightCache:
     def _build(self, params: Dict[str, Tensor], device) -> None:
         entries: List[hip.RemapEntry] = []
         for name, kind in self.convs.items():
-            w = params[name + ".weight"]
+            w = lookup(params, self.aliases, name + ".weight")
             co, ci, kk = conv_dims(kind, w)
             cow, cip, ciw, cop = _ru(co, 32), _ru(ci, 16), _ru(ci, 32), _ru(co, 16)
             if name not in self.fwd:
@@ -104,8 +113,9 @@ class WeightCache:
 
     def refresh(self, params: Dict[str, Tensor], device, force: bool = False) -> None:
         names = [n + ".weight" for n in self.convs] + [n + ".weight" for n in self.dwconvs]
-        ptrs = tuple(params[n].data_ptr() for n in names)
-        vers = (_WEIGHT_EPOCH[0],) + tuple(params[n]._version for n in names)
+        ws = [lookup(params, self.aliases, n) for n in names]
+        ptrs = tuple(w.data_ptr() for w in ws)
+        vers = (_WEIGHT_EPOCH[0],) + tuple(w._version for w in ws)
         if ptrs != self._ptrs:
             self._build(params, device)
             self._ptrs, self._vers = ptrs, ()
@@ -117,7 +127,9 @@ class WeightCache:
 class GradStore:
     """fp32 gradient accumulators in kernel layout (one flat zero-initialised buffer) and their torch-layout image."""
 
-    def __init__(self, convs: Dict[str, int], dwconvs: List[str], params: Dict[str, Tensor], device):
+    def __init__(self, convs: Dict[str, int], dwconvs: List[str], params: Dict[str, Tensor], device,
+                 aliases: Dict[str, Tuple[str, int, int]] = None):
+        self.aliases = aliases or {}
         self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         self.tlayout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = toff = 0
@@ -159,10 +171,25 @@ class GradStore:
     def zero(self):
         self.flat.zero_()
 
+    def _alias(self, name: str) -> Tuple[int, int, int]:
+        """(offset, rows, row length) of a logical weight that is a row range of a parameter kept in its torch layout
+        (out x in, which is also the kernel layout of a pointwise weight gradient when `in` is a multiple of 16)"""
+        real, r0, rows = self.aliases[name]
+        off, shp = self.layout[real]
+        k = _numel(self.tlayout[real][1][1:])
+        if len(shp) != 1 or k % 16:
+            raise ValueError(f"{real}: a row range of this parameter cannot be addressed in the gradient buffer")
+        return off + r0 * k, rows, k
+
     def offset(self, name: str) -> int:
+        if name not in self.layout:
+            return self._alias(name)[0]
         return self.layout[name][0]
 
     def __getitem__(self, name: str) -> Tensor:
+        if name not in self.views:
+            off, rows, k = self._alias(name)
+            self.views[name] = self.flat[off:off + rows * k].view(1, rows, k)
         return self.views[name]
 
     def unpack(self) -> Dict[str, Tensor]:

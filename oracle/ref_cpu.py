@@ -56,6 +56,11 @@ class UNetCfg:
     activation: str = "gelu"
     base_groups_norm: int = 4
     time_norm: float = 100.0
+    # Stages whose Down/Up blocks carry a self-attention ConditionalModule at layers[1], the place where the
+    # reference's commented-out construction would insert it (constituent_blocks.py:92-101,194-203).  The reference
+    # itself never builds it, so anything with a non-empty tuple here is pinned at the ConditionalModule level only.
+    attention_stages: Sequence[int] = ()
+    attention_depth: int = 1
 
     @property
     def groups(self) -> int:          # constituent_blocks.py:68-72, conv_block.py:67-71
@@ -196,22 +201,39 @@ def sir_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks)
     return _r(o)
 
 
-def down_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
-    """DownBlock.forward (constituent_blocks.py:63-90,135-147)."""
+def _attend(p: Params, pre: str, z: Tensor, depth: int, act) -> Tensor:
+    """The isinstance(layer, ConditionalModule) branch of the blocks' forward (constituent_blocks.py:137-143,233-239):
+    flatten to tokens, run the module with condition = the tokens themselves, unflatten."""
+    n, c, h, w = z.shape
+    tok = _r(z).flatten(2).transpose(1, 2)
+    tok = conditional_module(p, pre, tok, tok, depth, act)
+    return _r(tok.transpose(1, 2).reshape(n, c, h, w))
+
+
+def down_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks, attn_depth: int = 0) -> Tensor:
+    """DownBlock.forward (constituent_blocks.py:63-90,135-147); attn_depth > 0 = a ConditionalModule at layers[1]."""
     z = conv_gn_act(p, pre + "layers.0.0.", pre + "layers.0.1.", x, groups, act, stride=2)
-    z = sir_block(p, pre + "layers.1.", z, groups, act, drop)
-    z = sir_block(p, pre + "layers.2.", z, groups, act, drop)
-    return conv_gn_act(p, pre + "layers.3.0.", pre + "layers.3.1.", z, groups, act)
+    k = 1
+    if attn_depth:
+        z = _attend(p, pre + "layers.1.", z, attn_depth, act)
+        k = 2
+    z = sir_block(p, f"{pre}layers.{k}.", z, groups, act, drop)
+    z = sir_block(p, f"{pre}layers.{k + 1}.", z, groups, act, drop)
+    return conv_gn_act(p, f"{pre}layers.{k + 2}.0.", f"{pre}layers.{k + 2}.1.", z, groups, act)
 
 
-def up_block(p: Params, pre: str, x: Tensor, skip: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
-    """UpBlock.forward (constituent_blocks.py:165-193,227-243)."""
+def up_block(p: Params, pre: str, x: Tensor, skip: Tensor, groups: int, act, drop: DropMasks, attn_depth: int = 0) -> Tensor:
+    """UpBlock.forward (constituent_blocks.py:165-193,227-243); attn_depth > 0 = a ConditionalModule at layers[1]."""
     z = torch.cat([x, skip], dim=1)
     z = conv_gn_act(p, pre + "layers.0.0.", pre + "layers.0.1.", z, groups, act)
-    z = sir_block(p, pre + "layers.1.", z, groups, act, drop)
-    z = conv_gn_act(p, pre + "layers.2.0.", pre + "layers.2.1.", z, groups, act, transposed=True)
-    z = sir_block(p, pre + "layers.3.", z, groups, act, drop)
-    return sir_block(p, pre + "layers.4.", z, groups, act, drop)
+    k = 1
+    if attn_depth:
+        z = _attend(p, pre + "layers.1.", z, attn_depth, act)
+        k = 2
+    z = sir_block(p, f"{pre}layers.{k}.", z, groups, act, drop)
+    z = conv_gn_act(p, f"{pre}layers.{k + 1}.0.", f"{pre}layers.{k + 1}.1.", z, groups, act, transposed=True)
+    z = sir_block(p, f"{pre}layers.{k + 2}.", z, groups, act, drop)
+    return sir_block(p, f"{pre}layers.{k + 3}.", z, groups, act, drop)
 
 
 # --------------------------------------------------------------------------- UNet
@@ -238,7 +260,8 @@ def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: st
     tap("enc.stem", z)
     skips = []
     for i in range(nst):
-        z = down_block(p, f"{enc}layers.{i}.", _r(z + embed_block(p, f"{enc}t_embeddings.{i}.", temb, act)), g, act, drop)
+        z = down_block(p, f"{enc}layers.{i}.", _r(z + embed_block(p, f"{enc}t_embeddings.{i}.", temb, act)), g, act, drop,
+                       cfg.attention_depth if i in cfg.attention_stages else 0)
         skips.append(tap(f"enc.stage{i}", z))
     z = _r(F.conv2d(z, _r(p[enc + "latent_layers.0.weight"]), p[enc + "latent_layers.0.bias"], padding=1))
     z = _r(act(F.group_norm(z, cfg.latent_groups, p[enc + "latent_layers.1.weight"], p[enc + "latent_layers.1.bias"], eps=1e-5)))
@@ -249,7 +272,8 @@ def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: st
     tap("dec.input", z)
     skips = skips[::-1]
     for i in range(nst):
-        z = up_block(p, f"{dec}layers.{i}.", _r(z + embed_block(p, f"{dec}t_embeddings.{i}.", temb, act)), skips[i], g, act, drop)
+        z = up_block(p, f"{dec}layers.{i}.", _r(z + embed_block(p, f"{dec}t_embeddings.{i}.", temb, act)), skips[i], g, act, drop,
+                     cfg.attention_depth if nst - 1 - i in cfg.attention_stages else 0)
         tap(f"dec.stage{i}", z)
     z = _r(act(_r(F.conv2d(z, _r(p[dec + "out_layers.0.weight"]), p[dec + "out_layers.0.bias"], padding=1))))
     z = F.conv2d(z, _r(p[dec + "out_layers.2.weight"]), p[dec + "out_layers.2.bias"], padding=1)
@@ -286,25 +310,67 @@ def conditional_module(p: Params, pre: str, query: Tensor, cond: Tensor, depth: 
     n, s, c = z.shape
     dh = c // num_heads
     for i in range(depth):
-        w_in, b_in = p[f"{pre}mhas.{i}.in_proj_weight"], p[f"{pre}mhas.{i}.in_proj_bias"]
-        q = F.linear(z, w_in[:c], b_in[:c])
-        k = F.linear(cond, w_in[c:2 * c], b_in[c:2 * c])
-        v = F.linear(cond, w_in[2 * c:], b_in[2 * c:])
+        m = f"{pre}mhas.{i}."
+        b_in = p[m + "in_proj_bias"]
+        if m + "in_proj_weight" in p:                   # kdim == vdim == C: one packed weight
+            w_in = p[m + "in_proj_weight"]
+            wq, wk, wv = w_in[:c], w_in[c:2 * c], w_in[2 * c:]
+        else:                                           # separate projections (torch keeps q/k/v_proj_weight then)
+            wq, wk, wv = p[m + "q_proj_weight"], p[m + "k_proj_weight"], p[m + "v_proj_weight"]
+        q = _r(F.linear(_r(z), _r(wq), b_in[:c]))
+        k = _r(F.linear(_r(cond), _r(wk), b_in[c:2 * c]))
+        v = _r(F.linear(_r(cond), _r(wv), b_in[2 * c:]))
         sk = cond.shape[1]
         q = q.view(n, s, num_heads, dh).transpose(1, 2)
         k = k.view(n, sk, num_heads, dh).transpose(1, 2)
         v = v.view(n, sk, num_heads, dh).transpose(1, 2)
         att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), dim=-1)
-        o = (att @ v).transpose(1, 2).reshape(n, s, c)
-        o = F.linear(o, p[f"{pre}mhas.{i}.out_proj.weight"], p[f"{pre}mhas.{i}.out_proj.bias"])
+        o = _r((att @ v).transpose(1, 2).reshape(n, s, c))
+        o = F.linear(o, _r(p[m + "out_proj.weight"]), p[m + "out_proj.bias"])
         # GroupNorm(1, C) over the (C, S, 1) view == joint norm over C*S per sample (:425-428)
-        r = (o + z).transpose(1, 2).unsqueeze(-1)
-        r = F.group_norm(r, 1, p[f"{pre}mha_norms.{i}.weight"], p[f"{pre}mha_norms.{i}.bias"], eps=1e-5)
-        h = F.linear(r.squeeze(-1).transpose(1, 2), p[f"{pre}linears.{i}.weight"], p[f"{pre}linears.{i}.bias"])
+        r = _r(o + z).transpose(1, 2).unsqueeze(-1)
+        r = _r(F.group_norm(r, 1, p[f"{pre}mha_norms.{i}.weight"], p[f"{pre}mha_norms.{i}.bias"], eps=1e-5))
+        h = _r(F.linear(r.squeeze(-1).transpose(1, 2), _r(p[f"{pre}linears.{i}.weight"]), p[f"{pre}linears.{i}.bias"]))
         h = act(h).transpose(1, 2).unsqueeze(-1) + r
-        h = F.group_norm(h, 1, p[f"{pre}linear_norms.{i}.weight"], p[f"{pre}linear_norms.{i}.bias"], eps=1e-5)
+        h = _r(F.group_norm(h, 1, p[f"{pre}linear_norms.{i}.weight"], p[f"{pre}linear_norms.{i}.bias"], eps=1e-5))
         z = h.squeeze(-1).transpose(1, 2)
     return z
+
+
+def conditional_shapes(pre: str, c: int, depth: int, kdim: Optional[int] = None) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys and shapes of ConditionalModule(c, act, depth, p, kdim, kdim) in registration order
+    (constituent_blocks.py:357-399; nn.MultiheadAttention registers in_proj_weight - or q/k/v_proj_weight when
+    kdim != embed_dim - then in_proj_bias, then out_proj)."""
+    kdim = c if kdim is None else kdim
+    out: Dict[str, Tuple[int, ...]] = {}
+    for i in range(depth):
+        m = f"{pre}mhas.{i}."
+        if kdim == c:
+            out[m + "in_proj_weight"] = (3 * c, c)
+        else:
+            out[m + "q_proj_weight"] = (c, c); out[m + "k_proj_weight"] = (c, kdim); out[m + "v_proj_weight"] = (c, kdim)
+        out[m + "in_proj_bias"] = (3 * c,); out[m + "out_proj.weight"] = (c, c); out[m + "out_proj.bias"] = (c,)
+    for name, shp in (("mha_norms", None), ("linears", (c, c)), ("linear_norms", None)):
+        for i in range(depth):
+            if shp:
+                out[f"{pre}{name}.{i}.weight"] = shp
+            else:
+                out[f"{pre}{name}.{i}.weight"] = (c,)
+            out[f"{pre}{name}.{i}.bias"] = (c,)
+    return out
+
+
+def hash_conditional_params(pre: str, c: int, depth: int, kdim: Optional[int] = None, seed_base: int = 700) -> Params:
+    """Deterministic ConditionalModule parameters (the rule tools/gen_golden.py used for conditional_module.pt)."""
+    p: Params = {}
+    for i, (k, shp) in enumerate(conditional_shapes(pre, c, depth, kdim).items()):
+        if len(shp) >= 2:
+            p[k] = hash_fill(shp, seed_base + i, (3.0 / shp[-1]) ** 0.5)
+        elif "norm" in k and k.endswith("weight"):
+            p[k] = hash_fill(shp, seed_base + i, 0.2, 1.0)
+        else:
+            p[k] = hash_fill(shp, seed_base + i, 0.1)
+    return p
 
 
 # --------------------------------------------------------------------------- loops
@@ -388,8 +454,12 @@ def param_shapes(cfg: UNetCfg, prefix: str = "model.") -> Dict[str, Tuple[int, .
     for i, (ci, co) in enumerate(zip(ins, st)):
         b = f"{e}layers.{i}.layers."
         conv(b + "0.0.", co, ci, 3); norm(b + "0.1.", co)
-        sir(b + "1.", co); sir(b + "2.", co)
-        conv(b + "3.0.", co, co, 3); norm(b + "3.1.", co)
+        k = 1
+        if i in cfg.attention_stages:
+            out.update(conditional_shapes(b + "1.", co, cfg.attention_depth))
+            k = 2
+        sir(f"{b}{k}.", co); sir(f"{b}{k + 1}.", co)
+        conv(f"{b}{k + 2}.0.", co, co, 3); norm(f"{b}{k + 2}.1.", co)
     for i, ci in enumerate(ins):
         embed(f"{e}t_embeddings.{i}.", ci)
     conv(e + "latent_layers.0.", cfg.latent_dim, st[-1], 3); norm(e + "latent_layers.1.", cfg.latent_dim)
@@ -401,9 +471,13 @@ def param_shapes(cfg: UNetCfg, prefix: str = "model.") -> Dict[str, Tuple[int, .
     for i, (ci, co) in enumerate(zip(rs, outs)):
         b = f"{d}layers.{i}.layers."
         conv(b + "0.0.", ci, 2 * ci, 3); norm(b + "0.1.", ci)
-        sir(b + "1.", ci)
-        out[b + "2.0.weight"] = (ci, co, 2, 2); out[b + "2.0.bias"] = (co,); norm(b + "2.1.", co)
-        sir(b + "3.", co); sir(b + "4.", co)
+        k = 1
+        if len(st) - 1 - i in cfg.attention_stages:
+            out.update(conditional_shapes(b + "1.", ci, cfg.attention_depth))
+            k = 2
+        sir(f"{b}{k}.", ci)
+        out[f"{b}{k + 1}.0.weight"] = (ci, co, 2, 2); out[f"{b}{k + 1}.0.bias"] = (co,); norm(f"{b}{k + 1}.1.", co)
+        sir(f"{b}{k + 2}.", co); sir(f"{b}{k + 3}.", co)
     for i, ci in enumerate(rs):
         embed(f"{d}t_embeddings.{i}.", ci)
     conv(d + "out_layers.0.", rs[-1], rs[-1], 3)
@@ -425,7 +499,7 @@ def hash_params(cfg: UNetCfg, seed: int = 1, prefix: str = "model.", residual_ga
             fan_in = 1
             for dd in shp[1:]:
                 fan_in *= dd
-            if ".layers.2.0.weight" in k and len(shp) == 4 and shp[2] == 2:   # ConvTranspose2d (in,out,2,2)
+            if len(shp) == 4 and shp[2] == 2:                                 # ConvTranspose2d (in,out,2,2): the only 2x2 kernels
                 fan_in = shp[0]
             p[k] = hash_fill(shp, seed * 1000 + i, math.sqrt(3.0 / fan_in))
         elif k.endswith("weight"):

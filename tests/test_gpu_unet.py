@@ -29,11 +29,13 @@ YAML = dict(stages_channels=[32, 64, 128, 256], expand_factor=2, drop_p=0.1, T=1
             base_groups_norm=4, initializer="he_normal", dtype=None)
 
 
-def build(dev, img_channels=3, activation="gelu", drop_p=0.0, seed=1, head_gain=1.0):
+def build(dev, img_channels=3, activation="gelu", drop_p=0.0, seed=1, head_gain=1.0, attention_stages=()):
     kw = dict(YAML, activation=activation, drop_p=drop_p)
+    if attention_stages:
+        kw["attention_stages"] = list(attention_stages)
     m = dm_ddpm.DDPM(dm_unets.BaseUNet, **kw, is_conditional=False, img_channels=img_channels, reconstruction_method="mse",
                      latent_dim=512, device=dev)
-    cfg = O.UNetCfg(img_channels=img_channels, activation=activation, drop_p=drop_p)
+    cfg = O.UNetCfg(img_channels=img_channels, activation=activation, drop_p=drop_p, attention_stages=tuple(attention_stages))
     p = O.hash_params(cfg, seed=seed, head_gain=head_gain)
     m.load_state_dict(p)
     return m.to(dev), cfg, p
@@ -117,6 +119,32 @@ def test_forward_backward_vs_oracle_64x64(dev):
         ref = O.unet_forward(p, cfg, x_t_ref, t)
     pred = m(x_t, t.to(dev))
     assert l2_err(pred.detach().cpu(), ref) < 5e-2
+    loss_ref, grads_ref = O.train_step_grads(p, cfg, s, x0, t, noise)
+    loss = ELBOLoss("mse")(m, t.to(dev), pred, x0.to(dev))["Loss"]
+    assert abs(loss.item() - loss_ref.item()) < 1e-2 * abs(loss_ref.item())
+    loss.backward()
+    check_grads(((k, prm.grad) for k, prm in m.named_parameters()), grads_ref)
+
+
+def test_forward_backward_with_attention_stages_vs_oracle(dev):
+    """Self-attention ConditionalModules at stages 1 and 2 (16x16 tokens of width 64, 8x8 tokens of width 128 for a 64x64
+    input), in the Down and the Up block of each.  The reference never builds this network (its insertion code is commented
+    out), so the whole-network oracle here is the composition of parts that are each pinned to the reference: parity of the
+    composition itself is unpinned."""
+    m, cfg, p = build(dev, 3, "gelu", attention_stages=(1, 2))
+    assert len(m.state_dict()) == 350 + 4 * 10
+    m.eval()
+    n = 2
+    x0 = hash_uniform((n, 3, 64, 64), 21) * 2 - 1
+    t = torch.tensor([7, 99])
+    noise = hash_normal((n, 3, 64, 64), 22)
+    s = O.make_schedule(120, 0.25)
+    x_t_ref = O.q_sample(s, x0, t, noise)
+    x_t = m.q(x0.to(dev), t.to(dev), noise=noise.to(dev))
+    with torch.no_grad():
+        ref = O.unet_forward(p, cfg, x_t_ref, t)
+    pred = m(x_t, t.to(dev))
+    assert l2_err(pred.detach().cpu(), ref) < 5e-2, l2_err(pred.detach().cpu(), ref)
     loss_ref, grads_ref = O.train_step_grads(p, cfg, s, x0, t, noise)
     loss = ELBOLoss("mse")(m, t.to(dev), pred, x0.to(dev))["Loss"]
     assert abs(loss.item() - loss_ref.item()) < 1e-2 * abs(loss_ref.item())

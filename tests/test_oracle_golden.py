@@ -151,3 +151,24 @@ def test_conditional_module(golden):
             p[k] = O.hash_fill(shp, g["param_seed_base"] + i, 0.1)
     y = O.conditional_module(p, "", g["q"], g["q"], g["depth"], O.act_fn("gelu"), g["heads"])
     close(y, g["y_self"], 2e-4, 2e-5)
+    assert list(O.conditional_shapes("", g["C"], g["depth"]).keys()) == list(g["shapes"].keys())
+
+
+@pytest.mark.parametrize("name", ["self_c128_s256", "self_c32_s256", "cross_packed", "cross_separate"])
+def test_conditional_module_gradients(golden, name):
+    """forward and autograd gradients of the restated ConditionalModule against the reference's, for self-attention and
+    for cross-attention with packed and with separate projection weights"""
+    c = golden("conditional_module.pt")["cases"][name]
+    p = O.hash_conditional_params("", c["C"], c["depth"], c["kdim"], seed_base=c["param_seed_base"])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    q = hash_normal((2, c["S"], c["C"]), c["q_seed"]).requires_grad_(True)
+    cond = q if c["Sk"] is None else hash_normal((2, c["Sk"], c["kdim"]), c["cond_seed"]).requires_grad_(True)
+    y = O.conditional_module(leaves, "", q, cond, c["depth"], O.act_fn(c["activation"]))
+    close(y.detach(), c["y"], 2e-4, 2e-5)
+    ins = [q] + ([] if c["Sk"] is None else [cond])
+    grads = torch.autograd.grad(y, ins + list(leaves.values()), hash_normal(tuple(y.shape), c["gy_seed"]))
+    close(grads[0], c["dq"], 1e-3, 1e-4)
+    if c["Sk"] is not None:
+        close(grads[1], c["dcond"], 1e-3, 1e-4)
+    for k, gk in zip(leaves, grads[len(ins):]):
+        close(gk, c["dparams"][k], 1e-3, 2e-4)

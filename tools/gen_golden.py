@@ -296,13 +296,35 @@ def gen_conditional():
     q = hash_normal((2, 64, c), 801)
     with torch.no_grad():
         y_self = mod(q, q)
-    save("conditional_module.pt", {"C": c, "depth": depth, "heads": 8, "param_seed_base": 700,
-                                   "shapes": {k: tuple(v.shape) for k, v in sd.items()}, "q": q, "y_self": y_self})
+    out = {"C": c, "depth": depth, "heads": 8, "param_seed_base": 700,
+           "shapes": {k: tuple(v.shape) for k, v in sd.items()}, "q": q, "y_self": y_self, "cases": {}}
+    # forward + gradients: self-attention at the 16x16 stage widths, cross-attention with a packed in_proj_weight
+    # (kdim == C) and with separate q/k/v projection weights (kdim != C)
+    for name, cc, dep, s_q, s_k, kdim, act in (("self_c128_s256", 128, 1, 256, None, None, "gelu"), ("self_c32_s256", 32, 1, 256, None, None, "silu"),
+                                               ("cross_packed", 128, 2, 64, 40, 128, "gelu"), ("cross_separate", 64, 1, 64, 24, 48, "gelu")):
+        kd = cc if kdim is None else kdim
+        mod = ref_blocks.ConditionalModule(cc, act, dep, 0.0, kd, kd).eval()
+        params = O.hash_conditional_params("", cc, dep, kd, seed_base=900)
+        assert list(mod.state_dict()) == list(params), (list(mod.state_dict()), list(params))
+        mod.load_state_dict(params)
+        qq = hash_normal((2, s_q, cc), 811).requires_grad_(True)
+        cond = qq if s_k is None else hash_normal((2, s_k, kd), 812).requires_grad_(True)
+        y = mod(qq, cond)
+        gy = hash_normal(tuple(y.shape), 813)
+        leaves = [qq] + ([] if s_k is None else [cond]) + list(mod.parameters())
+        grads = torch.autograd.grad(y, leaves, gy)
+        case = {"C": cc, "depth": dep, "S": s_q, "Sk": s_k, "kdim": kd, "activation": act, "param_seed_base": 900, "q_seed": 811,
+                "cond_seed": 812, "gy_seed": 813, "y": y.detach(), "dq": grads[0]}
+        rest = grads[1:]
+        if s_k is not None:
+            case["dcond"], rest = rest[0], rest[1:]
+        case["dparams"] = {k: g for (k, _), g in zip(mod.named_parameters(), rest)}
+        out["cases"][name] = case
+    save("conditional_module.pt", out)
 
 
 if __name__ == "__main__":
-    gen_schedule_and_ops()
-    gen_blocks()
-    gen_unet_full()
-    gen_sample_chain()
-    gen_conditional()
+    only = sys.argv[1:]
+    for fn in (gen_schedule_and_ops, gen_blocks, gen_unet_full, gen_sample_chain, gen_conditional):
+        if not only or fn.__name__ in only:
+            fn()
