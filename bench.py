@@ -79,21 +79,36 @@ def main():
     ap.add_argument("--sample-batch", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam(capturable) instead of the fused flat Adam")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after backward instead of the overlapped two-phase exchange")
+    ap.add_argument("--bucket-mb", type=int, default=64, help="largest single all-reduce message")
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", default="", help="write a per-launch-shape timing table of the roofline pass to this file")
     a = ap.parse_args()
+    # libraries (the collective library's version banner, for one) write to stdout: keep the real stdout for the one JSON
+    # line and send everything else to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1
+    # DDPM_BENCH_REHEARSE_DP=1 takes the N > 1 code path (process group, overlapped exchange with real RCCL calls) with a
+    # single rank, to rehearse it on a one-GPU box; the reported line is then not a scaling result
+    rehearse = world == 1 and os.environ.get("DDPM_BENCH_REHEARSE_DP") == "1"
+    dist = world > 1 or rehearse
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            td.init_process_group("nccl", device_id=dev)
 
     m = build_model(dev, a.channels)
     m.train()
@@ -101,13 +116,18 @@ def main():
     opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=0) if not a.torch_adam else torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
     x0 = (torch.rand(a.batch, a.channels, a.size, a.size, device=dev) * 2 - 1)
 
-    after = None
     if dist:
+        # data parallel: full replica per GPU; the decoder half of the flat gradient buffer is all-reduced (RCCL, AVG) while
+        # the encoder half of the backward pass still runs, the encoder half right after it
         from dm_amd.runtime.dp import GradReducer
-        reducer = GradReducer(list(m.parameters()), world)
+        reducer = GradReducer(list(m.parameters()), 2 if rehearse else world, bucket_bytes=a.bucket_mb << 20)
         reducer.broadcast_parameters()
-        after = reducer.allreduce
-    step = graphs.GraphedTrainStep(m, crit, opt, x0, after_backward=after, use_graph=not a.no_graph)
+        if a.no_overlap:
+            step = graphs.GraphedTrainStep(m, crit, opt, x0, after_backward=reducer.allreduce, use_graph=not a.no_graph)
+        else:
+            step = graphs.OverlappedTrainStep(m, crit, opt, x0, reducer, use_graph=not a.no_graph)
+    else:
+        step = graphs.GraphedTrainStep(m, crit, opt, x0, use_graph=not a.no_graph)
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,7 +157,9 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"DDPM train step, {a.size}x{a.size}x{a.channels} (FashionMNIST-shaped), batch {a.batch}/GPU, "
                                f"stages [32,64,128,256], T=120, drop_p=0.1, Adam (lr 1e-3), gradient_accumulation_steps=1",
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph,
+                   "grad_exchange": ("none" if not dist else "one all-reduce after backward" if a.no_overlap else
+                                     "2 flat buckets (decoder, encoder), first overlapped with the encoder's backward")},
         "final_loss": loss,
     }
 
@@ -164,7 +186,7 @@ def main():
     if rank == 0 and not a.no_roofline:
         from dm_amd.runtime import roofline
         rows = [] if a.detail else None
-        out["roofline"] = roofline.measure(step._body, traffic_file=os.path.join(ROOT, "profiles", "hbm_traffic.json"), detail=rows)
+        out["roofline"] = roofline.measure(step.local_body, traffic_file=os.path.join(ROOT, "profiles", "hbm_traffic.json"), detail=rows)
         if rows:
             with open(a.detail, "w") as f:
                 for k, cnt, us, gbs, tf in sorted(rows, key=lambda r: -r[1] * r[2]):
@@ -172,7 +194,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.channels, a.size, 64, 3)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         td.destroy_process_group()
 

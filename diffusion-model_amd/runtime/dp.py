@@ -1,4 +1,4 @@
-"""Data-parallel gradient exchange: one process per GPU, one flat all-reduce per step over RCCL (xGMI).
+"""Data-parallel gradient exchange: one process per GPU, flat all-reduces over RCCL (xGMI), overlapped with backward.
 
 The reference shards the batch with torch DDP under `accelerate` (train_ddpm.py:24-80, base_trainer.py:48-58,151-158
 there): per-parameter autograd hooks feed 25 MB buckets.  Here the whole denoiser backward is one autograd node whose
@@ -6,6 +6,10 @@ there): per-parameter autograd hooks feed 25 MB buckets.  Here the whole denoise
 exchange is a single collective on that buffer with no packing pass; averaging is folded into the collective (AVG)
 where the backend has it.  xGMI rings are per-link bound, so few large messages beat many small ones: `bucket_bytes`
 defaults to one bucket for this network and only splits buffers larger than that.
+
+Overlap: the engine's backward pass runs in two phases (head + decoder, then encoder); runtime/graphs.py's
+OverlappedTrainStep hands the decoder half of the flat buffer to start_range() as soon as phase 0 has produced it, so that
+exchange travels while phase 1 computes; only the encoder half's exchange is exposed.
 
 Gradients that are not views of one buffer (a foreign autograd graph, a CPU model under gloo) are gathered into the
 reducer's own flat buffer, reduced there and scattered back."""
@@ -54,6 +58,28 @@ class GradReducer:
             w.wait()
         if not self._avg:
             flat.mul_(1.0 / self.world)
+
+    @torch.no_grad()
+    def start_range(self, flat: Tensor, lo: int, hi: int):
+        """Begin averaging flat[lo:hi] over the ranks without blocking: the collective is ordered after the work already
+        queued on the current stream and runs on the communicator's own stream, so kernels launched afterwards (the rest of
+        the backward pass) overlap with it.  The range goes out in `bucket_bytes` pieces.  Returns a handle for finish()."""
+        if self.world == 1:
+            return None
+        op = td.ReduceOp.AVG if self._avg else td.ReduceOp.SUM
+        piece = flat[lo:hi]
+        return (piece, [td.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets(piece)])
+
+    @torch.no_grad()
+    def finish(self, handle) -> None:
+        """Make the current stream wait for a start_range() exchange (host does not block on the GPU backend)."""
+        if handle is None:
+            return
+        piece, works = handle
+        for w in works:
+            w.wait()
+        if not self._avg:
+            piece.mul_(1.0 / self.world)
 
     @torch.no_grad()
     def allreduce(self) -> None:

@@ -158,11 +158,12 @@ class UNetEngine:
         self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together
         self._pin_eager: Optional[Tensor] = None      # pinned staging of the grouped-launch tables (eager steps reuse one)
         self._pin_event = None
-        self._pin_spare: Optional[Tensor] = None      # handed to a graph capture, which then owns it for good
+        self._pin_spares: List[Tensor] = []           # handed one by one to graph captures, which then own them for good
         self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
-        self._reduce_tables: Dict[Tuple[int, int, int], Tuple[Tensor, int, int, int]] = {}
+        self.bucketed = False           # backward in two phases (decoder, then encoder) for overlapped gradient exchange
+        self._reduce_tables: Dict[Tuple, Tuple[Tensor, List[int], List[int], int]] = {}
 
     # ------------------------------------------------------------------------------------------ helpers
     def _site_sizes(self, n: int, h: int, w: int) -> List[int]:
@@ -536,30 +537,48 @@ class UNetEngine:
                 cur = out
             return Var(cur.v.view(shape_in)) if tape is None else _view_var(cur, shape_in, tape)
 
-        late: List[Callable[[], None]] = []           # backward work deferred to the end of the pass (before the reduction)
+        late: List[Tuple[int, Callable[[], None]]] = []   # (phase, backward work deferred to the flush of that phase)
+        bounds: List[int] = []                        # len(part_entries) at every flush so far
 
-        def finish():
-            for fn in late:
-                fn()
+        def flush(phase: int = 0, last: bool = True) -> bool:
+            """End a phase of the backward pass: run the work deferred to it, launch the weight-gradient problems collected
+            so far and fold the partial sums written so far into the gradient buffer.  Returns True when the gradients of
+            this phase are final in the gradient buffer.  On the first backward pass of a shape the workspace layout is
+            still being discovered, and everything is folded by the last flush."""
+            for ph, fn in late:
+                if ph == phase:
+                    fn()
             if pending:
                 self._launch_wgrad_group(pending, dev)
                 pending.clear()
-            if not part_entries and rkey not in self._reduce_tables:
-                return                                   # nothing was reduced in two stages in this pass
-            if rkey not in self._reduce_tables:
+            bounds.append(len(part_entries))
+            known = rkey in self._reduce_tables
+            if not known:
+                if not last:
+                    return False
+                if not part_entries:
+                    return True                          # nothing was reduced in two stages in this pass
                 tab = ops.reduce_table(part_entries, dev)
-                self._reduce_tables[rkey] = (tab, len(part_entries), max(e[4] for e in part_entries), part_cursor[0])
+                widths = [max([e[4] for e in part_entries[lo:hi]] or [1]) for lo, hi in zip([0] + bounds[:-1], bounds)]
+                self._reduce_tables[rkey] = (tab, list(bounds), widths, part_cursor[0])
                 part_ws[0] = torch.empty(part_cursor[0], device=dev, dtype=torch.float32)
                 for piece, off in first_time:
                     part_ws[0][off:off + piece.numel()].copy_(piece)
-            tab, ne, mw, _ = self._reduce_tables[rkey]
-            ops.reduce_rows(part_ws[0], G.flat, tab, ne, mw)
+                ops.reduce_rows(part_ws[0], G.flat, tab, len(part_entries), max(widths))
+                return True
+            tab, tb, widths, _ = self._reduce_tables[rkey]
+            k = len(bounds) - 1
+            assert k < len(tb) and tb[k] == bounds[k], "the backward pass took a different path than the one its reduction table was built for"
+            lo = tb[k - 1] if k else 0
+            if tb[k] > lo:
+                ops.reduce_rows(part_ws[0], G.flat, tab[lo:], tb[k] - lo, widths[k])
+            return True
 
         from types import SimpleNamespace
         return SimpleNamespace(P=P, G=G, wc=wc, tape=tape, conv_unit=conv_unit, conv_bwd=conv_bwd, dw_unit=dw_unit, sir=sir, embed=embed,
                                attn_module=attn_module,
                                wgrad=wgrad, part_alloc=part_alloc, part_entries=part_entries, gn_partials=gn_partials, tap=tap, late=late,
-                               finish=finish, mscale=mscale)
+                               finish=flush, mscale=mscale)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, params: Dict[str, Tensor], x: Tensor, t: Tensor, train: bool, record: bool,
@@ -575,7 +594,7 @@ class UNetEngine:
         if h % (1 << nst) or w % (1 << nst):
             raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
         dev = x.device
-        c_ = self._open(params, n, dev, (n, h, w), train, record, masks, lambda: self._site_sizes(n, h, w), taps)
+        c_ = self._open(params, n, dev, (n, h, w, self.bucketed), train, record, masks, lambda: self._site_sizes(n, h, w), taps)
         P, G, wc, tape, late = c_.P, c_.G, c_.wc, c_.tape, c_.late
         conv_unit, sir, embed, wgrad, part_alloc, part_entries, tap, finish = (c_.conv_unit, c_.sir, c_.embed, c_.wgrad, c_.part_alloc,
                                                                                c_.part_entries, c_.tap, c_.finish)
@@ -600,22 +619,29 @@ class UNetEngine:
             for q, o in zip(enames, outs):
                 temb_vars[q] = Var(o)
             if tape is not None:
-                def bwd_embed():
-                    tiles = (n + 31) // 32
-                    db1s, db0s = [], []
-                    for q, c in zip(enames, ewidths):
-                        b1, o1 = part_alloc(tiles * c)
-                        part_entries.append((o1, G.offset(q + "layers.2.bias"), tiles, c, c))
-                        b0, o0 = part_alloc(tiles * 2 * c)
-                        part_entries.append((o0, G.offset(q + "layers.0.bias"), tiles, 2 * c, 2 * c))
-                        db1s.append(b1); db0s.append(b0)
-                    dts = [temb_vars[q].g for q in enames]
-                    dt16s, dzs = ops.embed_backward(dts, [sv_[0] for sv_ in esaved], [wc.dgrad[q + "layers.2"] for q in enames], sp.act,
-                                                    db1s, db0s)
-                    for q, c, sv_, d16, dz_ in zip(enames, ewidths, esaved, dt16s, dzs):
-                        wgrad(K11, sv_[1], d16, c, q + "layers.2")
-                        wgrad(K11, sin, dz_, 2 * c, q + "layers.0")
-                late.append(bwd_embed)
+                def bwd_embed(idx):
+                    """backward of the MLPs enames[i], i in idx, in one launch"""
+                    def run():
+                        tiles = (n + 31) // 32
+                        db1s, db0s = [], []
+                        for i in idx:
+                            q, c = enames[i], ewidths[i]
+                            b1, o1 = part_alloc(tiles * c)
+                            part_entries.append((o1, G.offset(q + "layers.2.bias"), tiles, c, c))
+                            b0, o0 = part_alloc(tiles * 2 * c)
+                            part_entries.append((o0, G.offset(q + "layers.0.bias"), tiles, 2 * c, 2 * c))
+                            db1s.append(b1); db0s.append(b0)
+                        dt16s, dzs = ops.embed_backward([temb_vars[enames[i]].g for i in idx], [esaved[i][0] for i in idx],
+                                                        [wc.dgrad[enames[i] + "layers.2"] for i in idx], sp.act, db1s, db0s)
+                        for i, d16, dz_ in zip(idx, dt16s, dzs):
+                            wgrad(K11, esaved[i][1], d16, ewidths[i], enames[i] + "layers.2")
+                            wgrad(K11, sin, dz_, 2 * ewidths[i], enames[i] + "layers.0")
+                    return run
+                if self.bucketed:       # the decoder's MLPs finish with the decoder's bucket (phase 0), the encoder's at the end
+                    late.append((0, bwd_embed(list(range(nst, 2 * nst)))))
+                    late.append((1, bwd_embed(list(range(nst)))))
+                else:
+                    late.append((0, bwd_embed(list(range(2 * nst)))))
         z = conv_unit(e + "stem_layers.0", Var(xin, need_grad=False), act=sp.act)
         tap("enc.stem", z.v)
         skips: List[Var] = []
@@ -634,6 +660,7 @@ class UNetEngine:
             tap(f"enc.stage{i}", z.v)
         z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
         tap("enc.latent", z.v)
+        mark = len(tape) if tape is not None else 0     # tape[mark:] is the decoder: its backward is phase 0 of a bucketed pass
         z = conv_unit(d + "decoder_input_layers.0", z, norm=d + "decoder_input_layers.1", groups=sp.groups, act=sp.act)
         tap("dec.input", z.v)
         for i in range(nst):
@@ -665,7 +692,7 @@ class UNetEngine:
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
             tape.append(bwd_head)
 
-            return out, (tape, out_holder, finish)
+            return out, (tape, out_holder, finish, mark)
         return out, None
 
     # ------------------------------------------------------------------------------------------ single blocks
@@ -684,12 +711,12 @@ class UNetEngine:
 
     def backward_program(self, ctx, dout: Tensor):
         """-> (gradients of the inputs (None where not needed), {parameter name: fp32 gradient in torch layout})"""
-        tape, out, finish, in_vars = ctx
+        tape, out, flush, in_vars = ctx
         self.grads.zero()
         out.g = dout
         for fn in reversed(tape):
             fn()
-        finish()
+        flush(0, True)
         tape.clear()
         return [v.g for v in in_vars], self.grads.unpack()
 
@@ -703,17 +730,21 @@ class UNetEngine:
         pinned = lambda: torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)                # noqa: E731
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:
-            host = self._pin_spare if self._pin_spare is not None and self._pin_spare.numel() >= nbytes else pinned()
-            self._pin_spare = None
+            # pinned memory cannot be allocated during capture: take a buffer set aside by an earlier eager step
+            fit = sorted((b.numel(), i) for i, b in enumerate(self._pin_spares) if b.numel() >= nbytes)
+            fit = [i for _, i in fit]                  # smallest sufficient buffer first
+            if not fit:
+                raise RuntimeError("no pinned staging buffer set aside for this capture: run the step eagerly at least once before capturing it")
+            host = self._pin_spares.pop(fit[0])
             self._pin_captured.append(host)
         else:
             if self._pin_eager is None or self._pin_eager.numel() < nbytes:
                 self._pin_eager = pinned()
             elif self._pin_event is not None:
-                self._pin_event.synchronize()          # the previous step's copy must have read the buffer
+                self._pin_event.synchronize()          # the previous launch's copy must have read the buffer
             host = self._pin_eager
-            if self._pin_spare is None or self._pin_spare.numel() < nbytes:
-                self._pin_spare = pinned()
+            if len([b for b in self._pin_spares if b.numel() >= nbytes]) < 4:   # a captured step may hold several group launches
+                self._pin_spares.append(pinned())
         hip.call("ddpm_conv_wgrad_group_plan", arr, n, host.data_ptr(), nbytes)
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         blob.copy_(host[:nbytes], non_blocking=True)
@@ -731,11 +762,33 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Replay the tape in reverse; returns {parameter name: fp32 gradient in torch layout}."""
-        tape, out_holder, finish = ctx
-        self.grads.zero()
-        out_holder.g = dout
-        for fn in reversed(tape):
-            fn()
-        finish()
-        tape.clear()
+        self.backward_phase(ctx, 0, dout)
+        if self.bucketed:
+            self.backward_phase(ctx, 1)
         return self.grads.unpack()
+
+    def backward_phase(self, ctx, phase: int, dout: Optional[Tensor] = None) -> bool:
+        """One phase of the backward pass.  Unbucketed engines have a single phase (0).  With `bucketed` set, phase 0 runs
+        the head and the decoder (after it every `decoder.*` gradient is final in the kernel-layout gradient buffer) and
+        phase 1 the encoder: a data-parallel driver can put the decoder's gradients on the wire while phase 1 computes.
+        Returns True when this phase's gradients are final (False only for phase 0 of the very first pass of a shape,
+        whose partial sums are folded by phase 1).  Gradients stay in self.grads (see GradStore.unpack_phase)."""
+        tape, out_holder, flush, mark = ctx
+        if phase == 0:
+            self.grads.zero()
+            out_holder.g = dout
+        if not self.bucketed:
+            for fn in reversed(tape):
+                fn()
+            ready = flush(0, True)
+            tape.clear()
+            return ready
+        if phase == 0:
+            for fn in reversed(tape[mark:]):
+                fn()
+            return flush(0, False)
+        for fn in reversed(tape[:mark]):
+            fn()
+        ready = flush(1, True)
+        tape.clear()
+        return ready

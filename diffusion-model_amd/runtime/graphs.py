@@ -81,6 +81,11 @@ class GraphedTrainStep:
             self.after_backward()
         self._back()
 
+    def local_body(self):
+        """one eager step without the gradient hook (per-kernel timing on one rank must not enter a collective)"""
+        self._front()
+        self._back()
+
     def replay(self) -> Tensor:
         if self.graph is None:
             self._body()
@@ -90,6 +95,128 @@ class GraphedTrainStep:
                 self.after_backward()
                 self.graph2.replay()
         return self.loss
+
+
+class OverlappedTrainStep:
+    """The same training step for data-parallel runs, with the gradient exchange overlapped with the backward pass.
+
+    The reference's DDP wrapper overlaps bucketed all-reduces with autograd's backward (base_trainer.py:95-100 there).  Here
+    the backward pass is the engine's tape, split in two phases, and the step is three HIP graphs with the collectives
+    launched between them on the communicator's stream:
+
+        graph A: randint t -> q -> UNet forward -> ELBO + its gradient -> backward phase 0 (head, decoder)
+                 -> decoder gradients to torch layout            | all-reduce(decoder half) starts
+        graph B: backward phase 1 (encoder) -> encoder gradients | ... and runs under graph B; all-reduce(encoder half)
+        graph C: wait for both -> fused Adam step
+
+    The step drives the engine directly (no autograd node), so it needs this package's DDPM/BaseUNet, ELBOLoss and
+    FusedAdam.  Parameter .grad tensors are bound once to views of the engine's persistent flat gradient buffer."""
+
+    def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer, *, use_graph: bool = True, warmup: int = 3):
+        self.core = ddpm.module if hasattr(ddpm, "module") else ddpm
+        self.criterion, self.optimizer, self.reducer, self.x0 = criterion, optimizer, reducer, x0
+        self.unet = self.core.model
+        self.eng = self.unet._get_engine()
+        self.eng.always_repack = True
+        self.eng.bucketed = True
+        self.loss = torch.zeros(1, device=x0.device)
+        self._ctx = None
+        self._ranges = [None, None]
+        self._bound = False
+        self.graphs = None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        if use_graph:
+            torch.cuda.synchronize()
+            gs = []
+            for fn, between in ((self._phase_a, lambda: self._exchange(0)), (self._phase_b, lambda: self._exchange(1)),
+                                (self._phase_c, None)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn()
+                gs.append(g)
+                if between is not None:
+                    between()
+                else:
+                    torch.cuda.synchronize()
+            self.graphs = gs
+
+    # ---- the three phases --------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _phase_a(self):
+        from . import hip
+        core, n = self.core, self.x0.shape[0]
+        t = torch.randint(1, core.T + 1, (n,), device=self.x0.device)
+        x_t = core.q(self.x0, t)
+        params = dict(zip(self.unet._param_names, self.unet.parameters()))
+        pred, self._ctx = self.eng.forward(params, x_t, t, train=self.unet.training, record=True)
+        table = self.criterion._table(core, pred.device)
+        chw = pred.numel() // n
+        flags = (int(self.criterion.bce), int(bool(self.criterion.use_elbo)))
+        hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr(self.x0), hip.ptr(t), hip.ptr(table), hip.ptr(self.loss), n, chw, *flags, hip.stream())
+        dpred = torch.empty_like(pred)
+        hip.call("ddpm_elbo_bwd", hip.ptr(pred), hip.ptr(self.x0), hip.ptr(t), hip.ptr(table), None, hip.ptr(dpred), n, chw, *flags, hip.stream())
+        self._ready0 = self.eng.backward_phase(self._ctx, 0, dpred)
+        if self._ready0:
+            self._ranges[0] = self.eng.grads.unpack_phase("decoder.", 0)
+
+    @torch.no_grad()
+    def _phase_b(self):
+        self.eng.backward_phase(self._ctx, 1)
+        self._ctx = None
+        if not self._ready0:                       # first pass of a shape: everything becomes final here
+            self._ranges[0] = self.eng.grads.unpack_phase("decoder.", 0)
+        self._ranges[1] = self.eng.grads.unpack_phase("decoder.", 1)
+        if not self._bound:
+            views = self.eng.grads.torch_views()
+            for name, p in zip(self.unet._param_names, self.unet.parameters()):
+                p.grad = views[name]
+            self._bound = True
+
+    @torch.no_grad()
+    def _phase_c(self):
+        self.optimizer.step()
+
+    def _exchange(self, k: int):
+        """start the exchange of half k (0: decoder, 1: encoder; after phase B also finish both)"""
+        flat = self.eng.grads.flat_t
+        if k == 0:
+            self._h0 = self.reducer.start_range(flat, *self._ranges[0]) if self._ready0 else None
+            return
+        if not self._ready0:
+            self._h0 = self.reducer.start_range(flat, *self._ranges[0])
+        h1 = self.reducer.start_range(flat, *self._ranges[1])
+        self.reducer.finish(self._h0)
+        self.reducer.finish(h1)
+
+    def _body(self):
+        self._phase_a()
+        self._exchange(0)
+        self._phase_b()
+        self._exchange(1)
+        self._phase_c()
+
+    def local_body(self):
+        """one eager step without the exchange (per-kernel timing on one rank must not enter a collective)"""
+        self._phase_a()
+        self._phase_b()
+        self._phase_c()
+
+    def replay(self) -> Tensor:
+        if self.graphs is None:
+            self._body()
+        else:
+            a, b, c = self.graphs
+            a.replay()
+            self._exchange(0)
+            b.replay()
+            self._exchange(1)
+            c.replay()
+        return self.loss[0]
 
 
 class GraphedSampler:

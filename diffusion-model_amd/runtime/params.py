@@ -166,7 +166,9 @@ class GradStore:
         self.views = {k: self.flat[o:o + _numel(s)].view(s) for k, (o, s) in self.layout.items()}
         fa, fb = self.flat.data_ptr(), self.flat_t.data_ptr()
         entries = [_entry(fa + 4 * o, fb + 4 * t, S, R, K, Rv, Kv, a_r, a_k, offs, False) for (o, t, S, R, K, Rv, Kv, a_r, a_k, offs) in recipe]
+        self._entries, self._names, self._device = entries, list(params.keys()), device
         self._table, self._chunks, self._n = _to_device(entries, device)
+        self._phase_tables: Dict[Tuple[str, int], Tuple[Tensor, Tensor, int, int, int]] = {}
 
     def zero(self):
         self.flat.zero_()
@@ -191,6 +193,28 @@ class GradStore:
             off, rows, k = self._alias(name)
             self.views[name] = self.flat[off:off + rows * k].view(1, rows, k)
         return self.views[name]
+
+    def unpack_phase(self, prefix: str, phase: int) -> Tuple[int, int]:
+        """Kernel layout -> torch layout (into the persistent staging buffer flat_t, no copy) for one half of the parameters:
+        phase 0 = those whose name starts with `prefix`, phase 1 = the others.  Returns the element range [lo, hi) of flat_t
+        that the half occupies (it must be contiguous: parameters are laid out in registration order)."""
+        key = (prefix, phase)
+        if key not in self._phase_tables:
+            idx = [i for i, n in enumerate(self._names) if n.startswith(prefix) == (phase == 0)]
+            if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+                raise ValueError(f"parameters starting with {prefix!r} do not form one contiguous, non-empty run")
+            tab, chunks, n = _to_device([self._entries[i] for i in idx], self._device)
+            lo = self.tlayout[self._names[idx[0]]][0]
+            last = self.tlayout[self._names[idx[-1]]]
+            self._phase_tables[key] = (tab, chunks, n, lo, last[0] + _ru(_numel(last[1]), 4))
+        tab, chunks, n, lo, hi = self._phase_tables[key]
+        hip.call("ddpm_remap", hip.ptr(tab), hip.ptr(chunks), n, 0, hip.stream())
+        return lo, hi
+
+    def torch_views(self) -> Dict[str, Tensor]:
+        """{name: view of the persistent torch-layout staging buffer}: what unpack_phase fills (callers that bind these as
+        .grad must consume them before the next backward pass overwrites the buffer)"""
+        return {k: self.flat_t[o:o + _numel(shp)].view(shp) for k, (o, shp) in self.tlayout.items()}
 
     def unpack(self) -> Dict[str, Tensor]:
         """kernel layout -> torch layout for all parameters in one launch; returns {name: gradient}.  The gradients are

@@ -46,7 +46,15 @@ def _worker(rank, world, port, q):
         assert red.flat_view() is None
         red.allreduce()
         ok2 = all(torch.allclose(p.grad, torch.full_like(p, 0.0 if i == 1 else 10 * (1 + world) / 2 + i)) for i, p in enumerate(params))
-        q.put((rank, sums, ok1, ok2))
+        # (3) the overlapped path: two halves of the flat buffer exchanged as separate asynchronous ranges
+        flat.copy_(torch.arange(red.total, dtype=torch.float32) * (rank + 1))
+        cut = red.offs[2]
+        h_hi = red.start_range(flat, cut, red.total)
+        h_lo = red.start_range(flat, 0, cut)
+        red.finish(h_hi)
+        red.finish(h_lo)
+        ok3 = torch.allclose(flat, torch.arange(red.total, dtype=torch.float32) * (1 + world) / 2)
+        q.put((rank, sums, ok1, ok2 and ok3))
     finally:
         td.destroy_process_group()
 

@@ -349,3 +349,48 @@ def test_graphed_train_step_with_gradient_hook(dev):
     finally:
         torch.cuda.synchronize()
         td.destroy_process_group()
+
+
+def test_overlapped_train_step_matches_plain_step(dev):
+    """The bucketed data-parallel step (three graphs, backward in two phases, the decoder half of the gradients exchanged
+    while the encoder half is still being computed) must train exactly like the single-graph step: same seeds, same
+    weights after several steps up to summation order.  The exchange itself runs as one-rank RCCL all-reduces between
+    the graph replays."""
+    import os
+    import torch.distributed as td
+    from dm_amd.optimizer import FusedAdam
+    from dm_amd.runtime import graphs
+    from dm_amd.runtime.dp import GradReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        crit = ELBOLoss("mse")
+        x0 = (hash_uniform((8, 1, 32, 32), 5) * 2 - 1).to(dev)
+        out = []
+        for overlapped in (False, True):
+            torch.manual_seed(77)
+            m, _, _ = build(dev, 1, "gelu", drop_p=0.0)
+            m.train()
+            opt = FusedAdam(m.parameters(), lr=1e-3)
+            if overlapped:
+                red = GradReducer(list(m.parameters()), world=2)      # world=2: the collective path is taken on the one-rank group
+                step = graphs.OverlappedTrainStep(m, crit, opt, x0, red)
+                assert step.graphs is not None and step._ranges[0][1] == red.total and step._ranges[1][0] == 0
+                assert step._ranges[0][0] == step._ranges[1][1]
+            else:
+                step = graphs.GraphedTrainStep(m, crit, opt, x0)
+            losses = [step.replay().item() for _ in range(4)]
+            assert all(math.isfinite(v) for v in losses)
+            out.append((losses, [p.detach().clone() for p in m.parameters()], [k for k, _ in m.named_parameters()]))
+        (la, wa, names), (lb, wb, _) = out
+        assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(la, lb)), (la, lb)
+        for k, a, b in zip(names, wa, wb):
+            assert l2_err(b.cpu(), a.cpu()) < 1e-3, (k, l2_err(b.cpu(), a.cpu()))
+    except BaseException as exc:
+        import traceback
+        traceback.print_exc()
+        raise exc
+    finally:
+        torch.cuda.synchronize()
+        td.destroy_process_group()
