@@ -652,7 +652,7 @@ template <int C, int W>
 static int sir_launch(const SirArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
     constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) + (SIR_SLOTS * 2 * SIR_G + 2 * IPW * SIR_G + 15 * E + 3 * C) * 4;
-    static_assert(Ew<E, M>::NV <= 4 && Ew<C, M>::NV <= 4, "more passes than partial-sum slots");
+    static_assert(IPW == 1 || (Ew<E, M>::NV <= 4 && Ew<C, M>::NV <= 4), "more passes than partial-sum slots");
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     auto k = sir_fwd_kernel<C, W>;
     static bool attr_set = false;
@@ -671,7 +671,7 @@ extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int ac
     if (H != W || E != 2 * C || groups != SIR_G) return 0;
     if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU) return 0;
     return (C == 32 && W == 16) || (C == 64 && W == 8) || (C == 128 && W == 4) || (C == 256 && W == 2) ||
-           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32);
+           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16);
 }
 
 // 1 when the backward kernel (ddpm_sir_backward) also covers the shape
@@ -705,5 +705,6 @@ extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
     if (d->C == 128 && d->W == 4) return sir_launch<128, 4>(a, stream);
     if (d->C == 256 && d->W == 2) return sir_launch<256, 2>(a, stream);
     if (d->C == 128 && d->W == 8) return sir_launch<128, 8>(a, stream);
+    if (d->C == 64 && d->W == 16) return sir_launch<64, 16>(a, stream);
     return sir_launch<256, 4>(a, stream);
 }

@@ -810,5 +810,6 @@ extern "C" int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t strea
     if (d->C == 128 && d->W == 4) return sir_bwd_launch<128, 4>(a, stream);
     if (d->C == 256 && d->W == 2) return sir_bwd_launch<256, 2>(a, stream);
     if (d->C == 128 && d->W == 8) return sir_bwd_launch<128, 8>(a, stream);
+    if (d->C == 64 && d->W == 16) return sir_bwd_launch<64, 16>(a, stream);
     return sir_bwd_launch<256, 4>(a, stream);
 }
