@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam(capturable) instead of the fused flat Adam")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after backward instead of the overlapped two-phase exchange")
+    ap.add_argument("--phases", type=int, default=4, help="backward phases of the pipelined step: 2, 4, 5, or larger = one per stage")
+    ap.add_argument("--single-graph", action="store_true", help="N = 1: the whole step as one HIP graph on one stream (through autograd)")
     ap.add_argument("--bucket-mb", type=int, default=64, help="largest single all-reduce message")
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -125,9 +127,11 @@ def main():
         if a.no_overlap:
             step = graphs.GraphedTrainStep(m, crit, opt, x0, after_backward=reducer.allreduce, use_graph=not a.no_graph)
         else:
-            step = graphs.OverlappedTrainStep(m, crit, opt, x0, reducer, use_graph=not a.no_graph)
-    else:
+            step = graphs.OverlappedTrainStep(m, crit, opt, x0, reducer, phases=a.phases, use_graph=not a.no_graph)
+    elif a.single_graph or a.torch_adam:
         step = graphs.GraphedTrainStep(m, crit, opt, x0, use_graph=not a.no_graph)
+    else:
+        step = graphs.PipelinedTrainStep(m, crit, opt, x0, None, phases=a.phases, use_graph=not a.no_graph)
 
     def barrier():
         torch.cuda.synchronize()

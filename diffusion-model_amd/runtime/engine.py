@@ -155,6 +155,8 @@ class UNetEngine:
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
         self.fuse_embed = True          # all time-embedding MLPs in one forward and one backward launch
         self.wgrad_tiles_per_split = 8  # grouped weight gradients: 128-position tiles per position split
+        self.wgrad_tiles_last = 2       # the same for the last phase of a multi-phase backward, whose group launch runs alone
+        self._cur_tps = 8
         self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together
         self._pin_eager: Optional[Tensor] = None      # pinned staging of the grouped-launch tables (eager steps reuse one)
         self._pin_event = None
@@ -162,8 +164,19 @@ class UNetEngine:
         self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
-        self.bucketed = False           # backward in two phases (decoder, then encoder) for overlapped gradient exchange
+        self.phases = 1                 # backward in 1, 2 (decoder | encoder), 4 (each halved at its middle stage), 5 (the last
+                                        # of those cut again after the first encoder convolution) or, for any larger value,
+                                        # one phase per stage, so
+                                        # that a driver can run a phase's leaf work (weight gradients, exchange) beside the next phase
         self._reduce_tables: Dict[Tuple, Tuple[Tensor, List[int], List[int], int]] = {}
+
+    @property
+    def bucketed(self) -> bool:
+        return self.phases > 1
+
+    @bucketed.setter
+    def bucketed(self, v: bool) -> None:
+        self.phases = 2 if v else 1
 
     # ------------------------------------------------------------------------------------------ helpers
     def _site_sizes(self, n: int, h: int, w: int) -> List[int]:
@@ -258,7 +271,7 @@ class UNetEngine:
             """dense weight gradient: every position split stores its partial tile (no atomics on the few hot cache lines
             of a small weight block); the end-of-backward reduction folds the rows into the gradient buffer"""
             gw = G[name + ".weight"]
-            tps = self.wgrad_tiles_per_split if self.group_wgrad else 0
+            tps = self._cur_tps if self.group_wgrad else 0
             splits = ops.conv_wgrad_splits(kind, x0t, dyt, cout, x1=x1, tiles_per_split=tps)
             if splits <= 1 and not self.group_wgrad:
                 ops.conv_wgrad(kind, x0t, dyt, cout, gw, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale)
@@ -594,7 +607,7 @@ class UNetEngine:
         if h % (1 << nst) or w % (1 << nst):
             raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
         dev = x.device
-        c_ = self._open(params, n, dev, (n, h, w, self.bucketed), train, record, masks, lambda: self._site_sizes(n, h, w), taps)
+        c_ = self._open(params, n, dev, (n, h, w, self.phases), train, record, masks, lambda: self._site_sizes(n, h, w), taps)
         P, G, wc, tape, late = c_.P, c_.G, c_.wc, c_.tape, c_.late
         conv_unit, sir, embed, wgrad, part_alloc, part_entries, tap, finish = (c_.conv_unit, c_.sir, c_.embed, c_.wgrad, c_.part_alloc,
                                                                                c_.part_entries, c_.tap, c_.finish)
@@ -611,6 +624,8 @@ class UNetEngine:
         enames = [f"{e}t_embeddings.{i}." for i in range(nst)] + [f"{d}t_embeddings.{i}." for i in range(nst)]
         ewidths = [P[q + "layers.2.bias"].shape[0] for q in enames]
         temb_vars: Dict[str, Var] = {}
+        embed_bwd_factory = None
+        stage_seg: Dict[int, int] = {}                  # MLP index (encoder stages, then decoder stages) -> tape segment of its stage
         if (self.fuse_embed and sp.t_dim == 32 and len(enames) <= hip.EMBED_MAX and all(32 <= c <= 512 and c % 32 == 0 for c in ewidths)
                 and all(P[q + "layers.0.bias"].shape[0] == 2 * c for q, c in zip(enames, ewidths))):
             outs, esaved = ops.embed_forward(sin, [wc.fwd[q + "layers.0"] for q in enames], [P[q + "layers.0.bias"] for q in enames],
@@ -637,18 +652,21 @@ class UNetEngine:
                             wgrad(K11, esaved[i][1], d16, ewidths[i], enames[i] + "layers.2")
                             wgrad(K11, sin, dz_, 2 * ewidths[i], enames[i] + "layers.0")
                     return run
-                if self.bucketed:       # the decoder's MLPs finish with the decoder's bucket (phase 0), the encoder's at the end
-                    late.append((0, bwd_embed(list(range(nst, 2 * nst)))))
-                    late.append((1, bwd_embed(list(range(nst)))))
-                else:
-                    late.append((0, bwd_embed(list(range(2 * nst)))))
+                embed_bwd_factory = bwd_embed
         z = conv_unit(e + "stem_layers.0", Var(xin, need_grad=False), act=sp.act)
         tap("enc.stem", z.v)
         skips: List[Var] = []
+        marks: List[int] = []                           # tape positions where a backward phase ends (forward order)
+        cuts = self._phase_cuts(nst)
         for i in range(nst):
             b = f"{e}layers.{i}.layers."
+            if tape is not None and f"enc{i}" in cuts:
+                marks.append(len(tape))
+            stage_seg[i] = len(marks)
             temb = temb_vars.get(f"{e}t_embeddings.{i}.") or embed(f"{e}t_embeddings.{i}.", sin_v)
             a = conv_unit(b + "0.0", z, in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
+            if tape is not None and i == 0 and "enc0b" in cuts:
+                marks.append(len(tape))
             k = 1
             if i in sp.attn_stages:
                 a = c_.attn_module(b + "1.", a, None, sp.attn_depth, sp.attn_heads)
@@ -660,11 +678,15 @@ class UNetEngine:
             tap(f"enc.stage{i}", z.v)
         z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
         tap("enc.latent", z.v)
-        mark = len(tape) if tape is not None else 0     # tape[mark:] is the decoder: its backward is phase 0 of a bucketed pass
+        if tape is not None and "dec" in cuts:          # everything recorded from here on is the decoder
+            marks.append(len(tape))
         z = conv_unit(d + "decoder_input_layers.0", z, norm=d + "decoder_input_layers.1", groups=sp.groups, act=sp.act)
         tap("dec.input", z.v)
         for i in range(nst):
             b = f"{d}layers.{i}.layers."
+            if tape is not None and f"dec{i}" in cuts:
+                marks.append(len(tape))
+            stage_seg[nst + i] = len(marks)
             temb = temb_vars.get(f"{d}t_embeddings.{i}.") or embed(f"{d}t_embeddings.{i}.", sin_v)
             a = conv_unit(b + "0.0", z, x1=skips[nst - 1 - i], in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
             k = 1
@@ -691,8 +713,14 @@ class UNetEngine:
                 wgrad(K33, hfeat.v, dz, c_img, name)
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
             tape.append(bwd_head)
-
-            return out, (tape, out_holder, finish, mark)
+            if embed_bwd_factory is not None:
+                # an MLP's backward belongs to the phase that back-propagates its stage
+                by_phase: Dict[int, List[int]] = {}
+                for j, seg in stage_seg.items():
+                    by_phase.setdefault(len(marks) - seg, []).append(j)
+                for ph in sorted(by_phase):
+                    late.append((ph, embed_bwd_factory(sorted(by_phase[ph]))))
+            return out, (tape, out_holder, finish, marks)
         return out, None
 
     # ------------------------------------------------------------------------------------------ single blocks
@@ -712,6 +740,7 @@ class UNetEngine:
     def backward_program(self, ctx, dout: Tensor):
         """-> (gradients of the inputs (None where not needed), {parameter name: fp32 gradient in torch layout})"""
         tape, out, flush, in_vars = ctx
+        self._cur_tps = self.wgrad_tiles_per_split
         self.grads.zero()
         out.g = dout
         for fn in reversed(tape):
@@ -743,7 +772,7 @@ class UNetEngine:
             elif self._pin_event is not None:
                 self._pin_event.synchronize()          # the previous launch's copy must have read the buffer
             host = self._pin_eager
-            if len([b for b in self._pin_spares if b.numel() >= nbytes]) < 4:   # a captured step may hold several group launches
+            if len(self._pin_spares) < 64:             # one more for a later capture of this launch (a few KB each)
                 self._pin_spares.append(pinned())
         hip.call("ddpm_conv_wgrad_group_plan", arr, n, host.data_ptr(), nbytes)
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -760,35 +789,60 @@ class UNetEngine:
                     lambda: hip.call("ddpm_conv_wgrad_group_launch", host.data_ptr(), blob.data_ptr(), hip.stream()))
 
     # ------------------------------------------------------------------------------------------ backward
+    def _phase_cuts(self, nst: int) -> set:
+        """Where the tape is cut into backward phases: "enc{i}" / "dec{i}" = before encoder / decoder stage i (i >= 1), "dec" =
+        before the decoder's input layers, "enc0b" = after the first convolution of encoder stage 0 (keeps the LAST phase,
+        whose leaf work nothing can hide, down to that convolution and the stem)."""
+        ph, mid = self.phases, nst // 2
+        if ph <= 1:
+            return set()
+        if ph == 2:
+            return {"dec"}
+        if ph == 4:
+            return {"enc1", "dec", f"dec{mid}"} if nst > 1 else {"dec"}
+        if ph == 3:
+            return {f"enc{mid}", "dec", f"dec{mid}"}
+        if ph == 5:
+            return {"enc0b", f"enc{mid}", "dec", f"dec{mid}"}
+        return {"enc0b", "dec"} | {f"enc{i}" for i in range(1, nst)} | {f"dec{i}" for i in range(1, nst)}
+
+    def phase_layout(self) -> Tuple[int, int]:
+        """(number of backward phases, index of the phase after whose flush every `decoder.*` gradient is final)"""
+        cuts = self._phase_cuts(len(self.spec.stages))
+        return len(cuts) + 1, sum(1 for c in cuts if c.startswith("dec") and c != "dec")
+
     def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Replay the tape in reverse; returns {parameter name: fp32 gradient in torch layout}."""
-        self.backward_phase(ctx, 0, dout)
-        if self.bucketed:
-            self.backward_phase(ctx, 1)
+        for ph in range(len(ctx[3]) + 1):
+            self.backward_phase(ctx, ph, dout if ph == 0 else None)
         return self.grads.unpack()
 
-    def backward_phase(self, ctx, phase: int, dout: Optional[Tensor] = None) -> bool:
-        """One phase of the backward pass.  Unbucketed engines have a single phase (0).  With `bucketed` set, phase 0 runs
-        the head and the decoder (after it every `decoder.*` gradient is final in the kernel-layout gradient buffer) and
-        phase 1 the encoder: a data-parallel driver can put the decoder's gradients on the wire while phase 1 computes.
-        Returns True when this phase's gradients are final (False only for phase 0 of the very first pass of a shape,
-        whose partial sums are folded by phase 1).  Gradients stay in self.grads (see GradStore.unpack_phase)."""
-        tape, out_holder, flush, mark = ctx
+    def backward_data(self, ctx, phase: int, dout: Optional[Tensor] = None) -> None:
+        """The data-gradient chain of one backward phase (phase 0 starts from dout = gradient of the network output).
+        Phases run head-first: with 2 phases, 0 = head + decoder and 1 = encoder; with 4, each of those is halved at its
+        middle stage.  Leaf work (weight gradients, partial-sum folds, time-embedding MLPs) is only queued here."""
+        tape, out_holder, _, marks = ctx
+        self._cur_tps = self.wgrad_tiles_last if (marks and phase == len(marks)) else self.wgrad_tiles_per_split
         if phase == 0:
             self.grads.zero()
             out_holder.g = dout
-        if not self.bucketed:
-            for fn in reversed(tape):
-                fn()
-            ready = flush(0, True)
-            tape.clear()
-            return ready
-        if phase == 0:
-            for fn in reversed(tape[mark:]):
-                fn()
-            return flush(0, False)
-        for fn in reversed(tape[:mark]):
+        bounds = [0] + list(marks) + [len(tape)]
+        seg = len(bounds) - 2 - phase
+        for fn in reversed(tape[bounds[seg]:bounds[seg + 1]]):
             fn()
-        ready = flush(1, True)
-        tape.clear()
+
+    def backward_flush(self, ctx, phase: int) -> bool:
+        """The leaf work of a phase; after it the gradients of the phase's parameters are final in the kernel-layout
+        gradient buffer (returns False only on the very first pass of a shape, whose partial sums are all folded by the
+        last phase's flush).  Touches nothing a later phase's data-gradient chain writes, so a driver may run it on a
+        second stream beside that chain."""
+        tape, _, flush, marks = ctx
+        last = phase == len(marks)
+        ready = flush(phase, last)
+        if last:
+            tape.clear()
         return ready
+
+    def backward_phase(self, ctx, phase: int, dout: Optional[Tensor] = None) -> bool:
+        self.backward_data(ctx, phase, dout)
+        return self.backward_flush(ctx, phase)

@@ -97,57 +97,85 @@ class GraphedTrainStep:
         return self.loss
 
 
-class OverlappedTrainStep:
-    """The same training step for data-parallel runs, with the gradient exchange overlapped with the backward pass.
+class PipelinedTrainStep:
+    """The training step as a small pipeline of HIP graphs on two streams, driving the engine directly (no autograd node).
 
-    The reference's DDP wrapper overlaps bucketed all-reduces with autograd's backward (base_trainer.py:95-100 there).  Here
-    the backward pass is the engine's tape, split in two phases, and the step is three HIP graphs with the collectives
-    launched between them on the communicator's stream:
+    The backward pass is latency bound: its data-gradient chain is a long sequence of small dependent kernels that leaves
+    most of the machine idle, while the weight gradients, the partial-sum folds and the time-embedding MLPs are leaves that
+    nothing in the chain waits for.  The engine therefore runs the backward in `phases` pieces (head-first), and this
+    driver replays, per phase p, a graph M_p (data-gradient chain) on the main stream and a graph W_p (the phase's leaf
+    work) on a side stream, W_p beside M_{p+1}:
 
-        graph A: randint t -> q -> UNet forward -> ELBO + its gradient -> backward phase 0 (head, decoder)
-                 -> decoder gradients to torch layout            | all-reduce(decoder half) starts
-        graph B: backward phase 1 (encoder) -> encoder gradients | ... and runs under graph B; all-reduce(encoder half)
-        graph C: wait for both -> fused Adam step
+        main:  [A: t, q, forward, ELBO, M_0] [M_1] [M_2] [M_3] ........ wait side -> [C: Adam]
+        side:                         [W_0]  [W_1]  [W_2]  [W_3 + gradients to torch layout]
 
-    The step drives the engine directly (no autograd node), so it needs this package's DDPM/BaseUNet, ELBOLoss and
-    FusedAdam.  Parameter .grad tensors are bound once to views of the engine's persistent flat gradient buffer."""
+    (4 phases measured best: with one phase per stage the leaf launches become too small to keep the side stream ahead.
+    The last phase's leaf work runs alone, so its weight-gradient problems are cut into more, shorter position splits.)
 
-    def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer, *, use_graph: bool = True, warmup: int = 3):
+    Data parallel (reducer given): the reference's DDP wrapper overlaps bucketed all-reduces with autograd's backward
+    (base_trainer.py:95-100 there).  Here the `decoder.*` half of the flat gradient buffer is final after the middle
+    phase: it is converted to torch layout there and its all-reduce (RCCL, AVG) starts at once, travelling while the
+    encoder's phases compute; the `encoder.*` half follows after the last phase.  Collectives are launched eagerly
+    between graph replays, so nothing depends on capturing the collective library.
+
+    Needs this package's DDPM/BaseUNet, ELBOLoss and FusedAdam.  Parameter .grad tensors are bound once to views of the
+    engine's persistent flat gradient buffer.  Copy a new batch into `self.x0` before each replay()."""
+
+    def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer=None, *, phases: int = 4, use_graph: bool = True, warmup: int = 3):
         self.core = ddpm.module if hasattr(ddpm, "module") else ddpm
         self.criterion, self.optimizer, self.reducer, self.x0 = criterion, optimizer, reducer, x0
         self.unet = self.core.model
         self.eng = self.unet._get_engine()
         self.eng.always_repack = True
-        self.eng.bucketed = True
+        if int(phases) < 2:
+            raise ValueError("phases must be 2, 4 or larger (= one phase per stage)")
+        self.eng.phases = int(phases)
+        import os
+        self.eng.wgrad_tiles_last = int(os.environ.get("DDPM_TPS_LAST", self.eng.wgrad_tiles_last))
+        self.eng.wgrad_tiles_per_split = int(os.environ.get("DDPM_TPS", self.eng.wgrad_tiles_per_split))
+        self.K, self.mid = self.eng.phase_layout()      # mid: the phase after which the decoder half of the gradients is final
         self.loss = torch.zeros(1, device=x0.device)
         self._ctx = None
         self._ranges = [None, None]
+        self._ready = [False] * self.K
         self._bound = False
+        self._handles = []
         self.graphs = None
+        self.side = torch.cuda.Stream()
+        self.events = [torch.cuda.Event() for _ in range(self.K)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self._body()
+                self._run(None)
         torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
         if use_graph:
-            torch.cuda.synchronize()
-            gs = []
-            for fn, between in ((self._phase_a, lambda: self._exchange(0)), (self._phase_b, lambda: self._exchange(1)),
-                                (self._phase_c, None)):
+            # capture in execution order; every graph has its own memory pool, so what a side graph still reads is never
+            # handed to a later main graph's allocations
+            gm, gw = [], []
+            for p in range(self.K):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    fn()
-                gs.append(g)
-                if between is not None:
-                    between()
-                else:
-                    torch.cuda.synchronize()
-            self.graphs = gs
+                    self._main(p)
+                gm.append(g)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
+                    self._leaf(p)
+                gw.append(g)
+            gc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gc, capture_error_mode="thread_local"):
+                self._adam()
+            torch.cuda.synchronize()
+            self.graphs = (gm, gw, gc)
 
-    # ---- the three phases --------------------------------------------------------------------------------------------
+    # ---- pieces ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def _phase_a(self):
+    def _main(self, p: int):
+        """main-stream work of phase p (phase 0 also holds the whole forward pass)"""
+        if p > 0:
+            self.eng.backward_data(self._ctx, p)
+            return
         from . import hip
         core, n = self.core, self.x0.shape[0]
         t = torch.randint(1, core.T + 1, (n,), device=self.x0.device)
@@ -160,63 +188,90 @@ class OverlappedTrainStep:
         hip.call("ddpm_elbo_fwd", hip.ptr(pred), hip.ptr(self.x0), hip.ptr(t), hip.ptr(table), hip.ptr(self.loss), n, chw, *flags, hip.stream())
         dpred = torch.empty_like(pred)
         hip.call("ddpm_elbo_bwd", hip.ptr(pred), hip.ptr(self.x0), hip.ptr(t), hip.ptr(table), None, hip.ptr(dpred), n, chw, *flags, hip.stream())
-        self._ready0 = self.eng.backward_phase(self._ctx, 0, dpred)
-        if self._ready0:
-            self._ranges[0] = self.eng.grads.unpack_phase("decoder.", 0)
+        self.eng.backward_data(self._ctx, 0, dpred)
 
     @torch.no_grad()
-    def _phase_b(self):
-        self.eng.backward_phase(self._ctx, 1)
-        self._ctx = None
-        if not self._ready0:                       # first pass of a shape: everything becomes final here
-            self._ranges[0] = self.eng.grads.unpack_phase("decoder.", 0)
-        self._ranges[1] = self.eng.grads.unpack_phase("decoder.", 1)
-        if not self._bound:
-            views = self.eng.grads.torch_views()
-            for name, p in zip(self.unet._param_names, self.unet.parameters()):
-                p.grad = views[name]
-            self._bound = True
+    def _leaf(self, p: int):
+        """side-stream work of phase p: its weight gradients and folds; the halves of the gradient buffer go to torch layout
+        as soon as they are final"""
+        g = self.eng.grads
+        self._ready[p] = self.eng.backward_flush(self._ctx, p)
+        last = p == self.K - 1
+        if last:
+            self._ctx = None
+        if p == self.mid and self._ready[p]:
+            self._ranges[0] = g.unpack_phase("decoder.", 0)
+        if last:
+            if not self._ready[self.mid]:               # first pass of a shape: everything becomes final here
+                self._ranges[0] = g.unpack_phase("decoder.", 0)
+            self._ranges[1] = g.unpack_phase("decoder.", 1)
+            if not self._bound:
+                views = g.torch_views()
+                for name, prm in zip(self.unet._param_names, self.unet.parameters()):
+                    prm.grad = views[name]
+                self._bound = True
 
     @torch.no_grad()
-    def _phase_c(self):
+    def _adam(self):
         self.optimizer.step()
 
-    def _exchange(self, k: int):
-        """start the exchange of half k (0: decoder, 1: encoder; after phase B also finish both)"""
-        flat = self.eng.grads.flat_t
-        if k == 0:
-            self._h0 = self.reducer.start_range(flat, *self._ranges[0]) if self._ready0 else None
+    def _exchange(self, p: int):
+        """called with the side stream current, right after W_p was queued on it"""
+        if self.reducer is None:
             return
-        if not self._ready0:
-            self._h0 = self.reducer.start_range(flat, *self._ranges[0])
-        h1 = self.reducer.start_range(flat, *self._ranges[1])
-        self.reducer.finish(self._h0)
-        self.reducer.finish(h1)
+        flat = self.eng.grads.flat_t
+        last = p == self.K - 1
+        if p == self.mid and self._ready[p]:
+            self._handles.append(self.reducer.start_range(flat, *self._ranges[0]))
+        if last:
+            if not self._ready[self.mid]:
+                self._handles.append(self.reducer.start_range(flat, *self._ranges[0]))
+            self._handles.append(self.reducer.start_range(flat, *self._ranges[1]))
 
-    def _body(self):
-        self._phase_a()
-        self._exchange(0)
-        self._phase_b()
-        self._exchange(1)
-        self._phase_c()
+    def _run(self, graphs, exchange: bool = True):
+        main = torch.cuda.current_stream()
+        gm, gw, gc = graphs if graphs is not None else (None, None, None)
+        for p in range(self.K):
+            if gm is None:
+                self._main(p)
+            else:
+                gm[p].replay()
+            if gw is None:
+                # eager: everything on one stream (tensors handed from one stream to another would need the allocator's
+                # cross-stream bookkeeping; the captured graphs have private pools instead)
+                self._leaf(p)
+                if exchange:
+                    self._exchange(p)
+                continue
+            self.events[p].record(main)
+            self.side.wait_event(self.events[p])
+            with torch.cuda.stream(self.side):
+                gw[p].replay()
+                if exchange:
+                    self._exchange(p)
+        main.wait_stream(self.side)
+        for h in self._handles:
+            self.reducer.finish(h)
+        self._handles.clear()
+        if gc is None:
+            self._adam()
+        else:
+            gc.replay()
 
     def local_body(self):
         """one eager step without the exchange (per-kernel timing on one rank must not enter a collective)"""
-        self._phase_a()
-        self._phase_b()
-        self._phase_c()
+        self._run(None, exchange=False)
 
     def replay(self) -> Tensor:
-        if self.graphs is None:
-            self._body()
-        else:
-            a, b, c = self.graphs
-            a.replay()
-            self._exchange(0)
-            b.replay()
-            self._exchange(1)
-            c.replay()
+        self._run(self.graphs)
         return self.loss[0]
+
+
+class OverlappedTrainStep(PipelinedTrainStep):
+    """PipelinedTrainStep for data-parallel runs (the gradient exchange overlapped with the backward pass)."""
+
+    def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer, **kw):
+        super().__init__(ddpm, criterion, optimizer, x0, reducer, **kw)
 
 
 class GraphedSampler:

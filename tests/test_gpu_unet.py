@@ -352,10 +352,10 @@ def test_graphed_train_step_with_gradient_hook(dev):
 
 
 def test_overlapped_train_step_matches_plain_step(dev):
-    """The bucketed data-parallel step (three graphs, backward in two phases, the decoder half of the gradients exchanged
-    while the encoder half is still being computed) must train exactly like the single-graph step: same seeds, same
-    weights after several steps up to summation order.  The exchange itself runs as one-rank RCCL all-reduces between
-    the graph replays."""
+    """The pipelined step (backward in 2 or 4 phases, each phase's weight gradients on a second stream beside the next
+    phase's data-gradient chain, the decoder half of the gradients exchanged while the encoder half is still being
+    computed) must train exactly like the single-graph step: same seeds, same weights after several steps up to
+    summation order.  The exchange itself runs as one-rank RCCL all-reduces between the graph replays."""
     import os
     import torch.distributed as td
     from dm_amd.optimizer import FusedAdam
@@ -368,25 +368,29 @@ def test_overlapped_train_step_matches_plain_step(dev):
         crit = ELBOLoss("mse")
         x0 = (hash_uniform((8, 1, 32, 32), 5) * 2 - 1).to(dev)
         out = []
-        for overlapped in (False, True):
+        for mode in ("plain", "dp2", "dp5", "dp9", "single4"):
             torch.manual_seed(77)
             m, _, _ = build(dev, 1, "gelu", drop_p=0.0)
             m.train()
             opt = FusedAdam(m.parameters(), lr=1e-3)
-            if overlapped:
+            if mode == "plain":
+                step = graphs.GraphedTrainStep(m, crit, opt, x0)
+            elif mode == "single4":                                   # the pipelined step without an exchange
+                step = graphs.PipelinedTrainStep(m, crit, opt, x0, None, phases=4)
+            else:
                 red = GradReducer(list(m.parameters()), world=2)      # world=2: the collective path is taken on the one-rank group
-                step = graphs.OverlappedTrainStep(m, crit, opt, x0, red)
+                step = graphs.OverlappedTrainStep(m, crit, opt, x0, red, phases=int(mode[2]))
                 assert step.graphs is not None and step._ranges[0][1] == red.total and step._ranges[1][0] == 0
                 assert step._ranges[0][0] == step._ranges[1][1]
-            else:
-                step = graphs.GraphedTrainStep(m, crit, opt, x0)
             losses = [step.replay().item() for _ in range(4)]
             assert all(math.isfinite(v) for v in losses)
             out.append((losses, [p.detach().clone() for p in m.parameters()], [k for k, _ in m.named_parameters()]))
-        (la, wa, names), (lb, wb, _) = out
-        assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(la, lb)), (la, lb)
-        for k, a, b in zip(names, wa, wb):
-            assert l2_err(b.cpu(), a.cpu()) < 1e-3, (k, l2_err(b.cpu(), a.cpu()))
+        la, wa, names = out[0]
+        for lb, wb, _ in out[1:]:
+            assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(la, lb)), (la, lb)
+            for k, a, b in zip(names, wa, wb):
+                # different phase counts group (and so order) the fp32 partial sums differently; four Adam steps turn that into ~1e-3
+                assert l2_err(b.cpu(), a.cpu()) < 4e-3, (k, l2_err(b.cpu(), a.cpu()))
     except BaseException as exc:
         import traceback
         traceback.print_exc()
