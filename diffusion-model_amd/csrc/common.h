@@ -15,7 +15,11 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define DDPM_EHIP (-2)
 
 // Activation codes shared by every kernel and by the host side.
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5, ACT_HARDSIGMOID = 6, ACT_RELU6 = 7,
+       ACT_LEAKY_RELU = 8, ACT_SELU = 9, ACT_LAST = 9 };
+#define SELU_SCALE 1.0507009873554805f
+#define SELU_ALPHA 1.6732632423543772f
+#define LEAKY_SLOPE 0.05f   /* the reference registry's leaky_relu slope (neural_nets/activations.py:110) */
 
 void ddpm_set_error(const char* fmt, ...);
 int ddpm_check_launch(const char* what);
@@ -53,6 +57,10 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
         case ACT_RELU: return z > 0.f ? z : 0.f;
         case ACT_TANH: return tanhf(z);
         case ACT_SIGMOID: return sigmoid_fast(z);
+        case ACT_HARDSIGMOID: return fminf(fmaxf(z + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
+        case ACT_LEAKY_RELU: return z > 0.f ? z : LEAKY_SLOPE * z;
+        case ACT_SELU: return SELU_SCALE * (z > 0.f ? z : SELU_ALPHA * (__expf(z) - 1.f));
         default: return z;
     }
 }
@@ -74,6 +82,10 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
             const float s = sigmoid_fast(z);
             return s * (1.0f - s);
         }
+        case ACT_HARDSIGMOID: return (z > -3.f && z < 3.f) ? (1.f / 6.f) : 0.f;
+        case ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+        case ACT_LEAKY_RELU: return z > 0.f ? 1.f : LEAKY_SLOPE;
+        case ACT_SELU: return z > 0.f ? SELU_SCALE : SELU_SCALE * SELU_ALPHA * __expf(z);
         default: return 1.f;
     }
 }

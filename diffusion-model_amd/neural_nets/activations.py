@@ -1,12 +1,12 @@
 """Activation names of the reference registry (neural_nets/activations.py:102-114 there) mapped to the codes the
-fused HIP kernels implement.  The two activations with a learnable scalar (swish, hardswish) and the rarely used
-piecewise ones are not fused; asking for them is an error rather than a silent slow path."""
+HIP kernels implement.  All parameter-free ones are (gelu, silu and relu also inside the single-launch inverted-residual
+kernels, the others through the per-unit kernels); the two with a learnable scalar (swish, hardswish) are not: asking for
+them is an error rather than a silent slow path."""
 from __future__ import annotations
 
 from ..runtime import hip
 
-FUSED = {"gelu": hip.ACT["gelu"], "silu": hip.ACT["silu"], "relu": hip.ACT["relu"], "tanh": hip.ACT["tanh"],
-         "sigmoid": hip.ACT["sigmoid"]}
+FUSED = {k: hip.ACT[k] for k in ("gelu", "silu", "relu", "tanh", "sigmoid", "hardsigmoid", "relu6", "leaky_relu", "selu")}
 KNOWN = ["sigmoid", "hardsigmoid", "tanh", "swish", "hardswish", "relu", "relu6", "leaky_relu", "selu", "gelu", "silu"]
 
 

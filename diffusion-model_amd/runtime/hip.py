@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libddpm_hip.so")
 
-ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5}
+ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5, "hardsigmoid": 6, "relu6": 7, "leaky_relu": 8, "selu": 9}
 CONV_3X3_S1, CONV_3X3_S2, CONV_1X1, CONVT_2X2_S2, DGRAD_3X3_S2, DGRAD_CONVT_2X2 = range(6)
 OUT_BF16_NHWC, OUT_F32_NCHW = 0, 1
 

@@ -23,8 +23,10 @@ extern "C" {
 
 typedef void* ddpm_stream_t;
 
-/* activation codes (reference neural_nets/activations.py:102-114; only parameter-free ones are fused) */
-enum { DDPM_ACT_NONE = 0, DDPM_ACT_GELU = 1, DDPM_ACT_SILU = 2, DDPM_ACT_RELU = 3, DDPM_ACT_TANH = 4, DDPM_ACT_SIGMOID = 5 };
+/* activation codes (reference neural_nets/activations.py:102-114; the parameter-free ones; swish / hardswish carry a
+ * learnable scalar and are not implemented) */
+enum { DDPM_ACT_NONE = 0, DDPM_ACT_GELU = 1, DDPM_ACT_SILU = 2, DDPM_ACT_RELU = 3, DDPM_ACT_TANH = 4, DDPM_ACT_SIGMOID = 5,
+       DDPM_ACT_HARDSIGMOID = 6, DDPM_ACT_RELU6 = 7, DDPM_ACT_LEAKY_RELU = 8 /* slope 0.05 */, DDPM_ACT_SELU = 9 };
 
 /* convolution kinds handled by ddpm_conv_forward / ddpm_conv_wgrad */
 enum {

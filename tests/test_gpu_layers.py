@@ -18,6 +18,8 @@ def bits(k):
 
 @pytest.mark.parametrize("n,c,h,g,act", [(2, 32, 16, 16, "gelu"), (3, 64, 8, 16, "silu"), (2, 128, 4, 16, "gelu"),
                                           (5, 512, 2, 32, "gelu"), (2, 256, 2, 16, "none"), (2, 64, 32, 16, "gelu"),
+                                          (2, 64, 8, 16, "selu"), (2, 32, 8, 16, "leaky_relu"), (2, 32, 8, 16, "relu6"), (2, 64, 4, 16, "hardsigmoid"),
+                                          (2, 64, 4, 16, "relu"), (2, 64, 4, 16, "tanh"), (2, 64, 4, 16, "sigmoid"),
                                           (2, 32, 8, 0, "gelu")])
 def test_groupnorm_act_fwd_bwd(dev, n, c, h, g, act):
     x = r16(hash_normal((n, c, h, h), 1) * 1.5 + 0.7)

@@ -53,6 +53,15 @@ def test_no_cpu_fallback():
         SeparableInvertResidual(32, 32, expand_factor=2, activation="gelu")(torch.zeros(1, 32, 8, 8))
 
 
+def test_learnable_activations_are_rejected_loudly():
+    from dm_amd.neural_nets.activations import activation_code
+    for name in ("swish", "hardswish"):
+        with pytest.raises(NotImplementedError):
+            activation_code(name)
+    for name in ("gelu", "silu", "relu", "relu6", "leaky_relu", "selu", "hardsigmoid", "sigmoid", "tanh"):
+        assert activation_code(name) > 0
+
+
 def test_reference_error_conventions():
     with pytest.raises(ValueError):
         dm_ddpm.DDPM(dm_unets.BaseUNet, **dict(YAML, initializer="nope"), is_conditional=False, img_channels=1, reconstruction_method="mse",
