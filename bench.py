@@ -171,12 +171,18 @@ def main():
         m.eval()
         nb = a.sample_batch
         sampler = graphs.GraphedSampler(m, nb, (a.size, a.size), use_graph=not a.no_graph)
-        sampler.sample()
+        if dist:
+            # the job's images: every rank runs its own chains, one gather to rank 0 at the end of each job
+            from dm_amd.runtime.dp import sample_sharded
+            run_chain = lambda: sample_sharded(lambda n: sampler.sample(), nb * world)      # noqa: E731
+        else:
+            run_chain = sampler.sample
+        run_chain()
         barrier()
         t0 = time.perf_counter()
         reps = 2
         for _ in range(reps):
-            sampler.sample()
+            run_chain()
         barrier()
         ds = (time.perf_counter() - t0) / reps
         if dist:

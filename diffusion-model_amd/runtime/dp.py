@@ -124,3 +124,40 @@ def shard_range(total: int, rank: int, world: int):
     base, extra = divmod(total, world)
     b = rank * base + min(rank, extra)
     return b, b + base + (1 if rank < extra else 0)
+
+
+@torch.no_grad()
+def sample_sharded(sample_fn, total: int, group=None) -> Optional[Tensor]:
+    """Ancestral sampling of `total` images over all ranks: the chains are independent, so rank r runs
+    sample_fn(n_r) -> [n_r, C, H, W] for its contiguous share (shard_range) with no inter-GPU traffic during the T
+    steps, and ONE gather at the end brings the images to rank 0 (returned there in global order; None elsewhere).
+    sample_fn is e.g. `lambda n: ddpm.sample_tensor(n, shape)` or a GraphedSampler's sample (the reference samples on
+    rank 0 only, base_trainer.py:146-147,337-349).  Ranks draw their noise from their own generators (seed + rank)."""
+    world = td.get_world_size(group) if td.is_initialized() else 1
+    rank = td.get_rank(group) if td.is_initialized() else 0
+    b, e = shard_range(total, rank, world)
+    x = sample_fn(e - b) if e > b else None
+    if world == 1:
+        return x
+    # every rank must take part in the gather with equally shaped buffers: pad the shares to the largest one
+    most = (total + world - 1) // world
+    meta = torch.zeros(4, dtype=torch.long, device=x.device if x is not None else "cpu")
+    if x is not None:
+        meta.copy_(torch.tensor(x.shape, dtype=torch.long))
+    shapes = [torch.zeros_like(meta) for _ in range(world)]
+    td.all_gather(shapes, meta, group=group)
+    ref = next(s for s in shapes if s[0] > 0)
+    chw = tuple(int(v) for v in ref[1:])
+    dev = meta.device
+    buf = torch.zeros((most,) + chw, device=dev, dtype=torch.float32)
+    if x is not None:
+        buf[:e - b].copy_(x)
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    td.gather(buf, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = []
+    for r, part in enumerate(parts):
+        rb, re_ = shard_range(total, r, world)
+        out.append(part[:re_ - rb])
+    return torch.cat(out, dim=0)

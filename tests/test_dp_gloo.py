@@ -9,7 +9,7 @@ import torch.distributed as td
 import torch.multiprocessing as mp
 
 import dm_amd_bootstrap  # noqa: F401
-from dm_amd.runtime.dp import GradReducer, shard_range
+from dm_amd.runtime.dp import GradReducer, sample_sharded, shard_range
 
 SHAPES = [(5, 3), (7,), (2, 3, 3, 3), (1,)]
 
@@ -54,7 +54,12 @@ def _worker(rank, world, port, q):
         red.finish(h_hi)
         red.finish(h_lo)
         ok3 = torch.allclose(flat, torch.arange(red.total, dtype=torch.float32) * (1 + world) / 2)
-        q.put((rank, sums, ok1, ok2 and ok3))
+        # (4) sharded sampling: every rank produces its share (here: images filled with their global index), rank 0 receives all
+        total = 5
+        b0, _ = shard_range(total, rank, world)
+        imgs = sample_sharded(lambda n: (torch.arange(n, dtype=torch.float32) + b0).view(n, 1, 1, 1).expand(n, 1, 2, 2).contiguous(), total)
+        ok4 = (imgs is None) if rank else (imgs.shape == (total, 1, 2, 2) and torch.equal(imgs[:, 0, 0, 0], torch.arange(total, dtype=torch.float32)))
+        q.put((rank, sums, ok1, ok2 and ok3 and ok4))
     finally:
         td.destroy_process_group()
 
