@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--channels", type=int, default=1)
-    ap.add_argument("--sample-batch", type=int, default=256)
+    ap.add_argument("--sample-batch", type=int, default=1024, help="images per GPU per sampling job (BASELINE configs[3] samples 1024 images)")
+    ap.add_argument("--sample-streams", type=int, default=2, help="chains of sample-batch/streams images advanced on this many streams")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam(capturable) instead of the fused flat Adam")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after backward instead of the overlapped two-phase exchange")
@@ -170,7 +171,10 @@ def main():
     if not a.no_sample:
         m.eval()
         nb = a.sample_batch
-        sampler = graphs.GraphedSampler(m, nb, (a.size, a.size), use_graph=not a.no_graph)
+        if a.sample_streams > 1:
+            sampler = graphs.ConcurrentSampler(m, nb // a.sample_streams, (a.size, a.size), a.sample_streams, use_graph=not a.no_graph)
+        else:
+            sampler = graphs.GraphedSampler(m, nb, (a.size, a.size), use_graph=not a.no_graph)
         if dist:
             # the job's images: every rank runs its own chains, one gather to rank 0 at the end of each job
             from dm_amd.runtime.dp import sample_sharded
@@ -189,7 +193,7 @@ def main():
             tt = torch.tensor([ds], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             ds = tt.item()
-        out["sampling"] = {"value": nb * world / ds, "unit": "images/s", "chain_steps": 120, "batch_per_gpu": nb,
+        out["sampling"] = {"value": nb * world / ds, "unit": "images/s", "chain_steps": 120, "batch_per_gpu": nb, "streams": a.sample_streams,
                            "ms_per_chain": 1e3 * ds, "ms_per_step": 1e3 * ds / 120}
         m.train()
 

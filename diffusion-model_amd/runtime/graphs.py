@@ -274,13 +274,52 @@ class OverlappedTrainStep(PipelinedTrainStep):
         super().__init__(ddpm, criterion, optimizer, x0, reducer, **kw)
 
 
+class ConcurrentSampler:
+    """Several GraphedSamplers of `n` images each, their chains advanced in lockstep on separate streams.  Chains are
+    independent and a single chain's kernels leave most of the machine idle at the low-resolution stages, so chains on
+    different streams fill each other's gaps.  sample() returns the [streams * n, C, H, W] result."""
+
+    def __init__(self, ddpm, n: int, shape, streams: int = 2, *, use_graph: bool = True):
+        self.ddpm = ddpm
+        self.streams = [torch.cuda.Stream() for _ in range(streams)]
+        self.samplers = []
+        for s in self.streams:
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.samplers.append(GraphedSampler(ddpm, n, shape, use_graph=use_graph, stream=s, own_engine=True))
+        for s in self.streams:
+            torch.cuda.current_stream().wait_stream(s)
+
+    @torch.no_grad()
+    def sample(self) -> Tensor:
+        main = torch.cuda.current_stream()
+        for s, smp in zip(self.streams, self.samplers):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                smp.begin()
+        for _ in range(self.ddpm.T):
+            for s, smp in zip(self.streams, self.samplers):
+                with torch.cuda.stream(s):
+                    smp.step()
+        for s in self.streams:
+            main.wait_stream(s)
+        return torch.cat([smp.x for smp in self.samplers], dim=0)
+
+
 class GraphedSampler:
     """One sampling step (UNet forward + reverse step + t -= 1) captured once and replayed T times per chain."""
 
-    def __init__(self, ddpm, n: int, shape, *, use_graph: bool = True):
+    def __init__(self, ddpm, n: int, shape, *, use_graph: bool = True, stream=None, own_engine: bool = True):
         from torch.nn.modules.utils import _pair
         self.ddpm = ddpm
+        # The sampler drives an engine of its own: the kernel-layout weight copies are refreshed once per chain (begin)
+        # instead of inside every captured step, and samplers on different streams do not share per-shape bookkeeping.
+        self._engine = None
+        if own_engine:
+            from .engine import UNetEngine
+            self._engine = UNetEngine(ddpm.model.spec)
         dev = next(ddpm.parameters()).device
+        self.seed = torch.randint(0, 2 ** 62, (1,), device=dev, dtype=torch.long)     # this chain's noise stream
         self.x = torch.zeros((n, ddpm.img_channels) + _pair(shape), device=dev)
         self.x_next = torch.empty_like(self.x)
         self.times = torch.zeros(n, device=dev, dtype=torch.long)
@@ -295,26 +334,44 @@ class GraphedSampler:
         if use_graph:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+            with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="thread_local"), torch.no_grad():
                 self._body()
 
+    def _forward(self):
+        if self._engine is None:
+            return self.ddpm(self.x, self.times)
+        return self._engine.forward(self._params(), self.x, self.times, train=self.ddpm.model.training, record=False)[0]
+
+    def _params(self):
+        unet = self.ddpm.model
+        return dict(zip(unet._param_names, unet.parameters()))
+
+    def begin(self, x_T: Optional[Tensor] = None):
+        """start a chain: x_T (or fresh noise), t = T, current weights"""
+        if x_T is None:
+            self.x.normal_()
+        else:
+            self.x.copy_(x_T)
+        self.times.fill_(self.ddpm.T)
+        if self._engine is not None:
+            self._engine.wc.refresh(self._params(), self.x.device, force=True)
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+
     def _body(self):
-        x0_pred = self.ddpm(self.x, self.times)
-        self.ddpm.reverse_q(self.x, x0_pred, self.times, out=self.x_next, _sigmoid=self.bce)
+        x0_pred = self._forward()
+        self.ddpm.reverse_q(self.x, x0_pred, self.times, out=self.x_next, _sigmoid=self.bce, _seed=self.seed)
         self.x.copy_(self.x_next)
         self.times -= 1
 
     @torch.no_grad()
     def sample(self, x_T: Optional[Tensor] = None) -> Tensor:
         """Run the full T-step chain; returns the final tensor (before the (x+1)/2 rescale)."""
-        if x_T is None:
-            self.x.normal_()
-        else:
-            self.x.copy_(x_T)
-        self.times.fill_(self.ddpm.T)
+        self.begin(x_T)
         for _ in range(self.ddpm.T):
-            if self.graph is not None:
-                self.graph.replay()
-            else:
-                self._body()
+            self.step()
         return self.x

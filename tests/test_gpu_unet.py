@@ -427,3 +427,41 @@ def test_overlapped_train_step_matches_plain_step(dev):
     finally:
         torch.cuda.synchronize()
         td.destroy_process_group()
+
+
+def test_graphed_and_concurrent_samplers_follow_the_reference_chain(golden, dev):
+    """GraphedSampler (one captured step replayed T times, an engine of its own, weights refreshed per chain) and
+    ConcurrentSampler (two chains on two streams).  The eager sampling loop is pinned to the reference's chain by
+    test_sampling_chain_vs_reference_fixture; here: a captured step equals an eager step bit for bit (same x_T, same
+    noise seed), the sampler's own engine predicts exactly what the module predicts, a chain started after a weight
+    update uses the new weights, and concurrent chains draw different noise."""
+    from dm_amd.runtime import graphs
+    m, _, _ = build(dev, 1, "gelu", head_gain=0.3)
+    m.eval()
+    x_T = hash_normal((4, 1, 32, 32), 77).to(dev)
+    a = graphs.GraphedSampler(m, 4, (32, 32))
+    b = graphs.GraphedSampler(m, 4, (32, 32), use_graph=False)
+    b.seed.copy_(a.seed)
+    a.begin(x_T); b.begin(x_T)
+    a.step(); b.step()
+    assert torch.equal(a.x, b.x) and int(a.times[0]) == m.T - 1
+    # the eager module path gives the same prediction as the sampler's own engine
+    with torch.no_grad():
+        t = torch.full((4,), m.T, device=dev, dtype=torch.long)
+        pred = m(x_T, t)
+        c = graphs.GraphedSampler(m, 4, (32, 32), use_graph=False)
+        c.begin(x_T)
+        assert torch.equal(c._forward(), pred)
+    # weights changed after capture: the next chain must see them
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+    a.begin(x_T); b.begin(x_T)
+    b.seed.copy_(a.seed)
+    a.step(); b.step()
+    assert torch.equal(a.x, b.x)
+    cs = graphs.ConcurrentSampler(m, 2, (32, 32), streams=2)
+    out = cs.sample()
+    torch.cuda.synchronize()
+    assert out.shape == (4, 1, 32, 32) and torch.isfinite(out).all() and out.abs().max() < 3.0
+    assert not torch.equal(out[:2], out[2:])                         # the two chains draw different noise
