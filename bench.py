@@ -211,6 +211,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
+        barrier()                      # rank 0 may still be timing kernels: nobody tears the group down before it is done
         td.destroy_process_group()
 
 

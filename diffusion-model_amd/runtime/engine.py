@@ -310,6 +310,10 @@ class UNetEngine:
             wf = wc.fwd[name]
             bias = P[name + ".bias"]
             cout = bias.shape[0]
+            if norm is None and tape is None and res is None and out_mask is None:
+                # inference, no normalisation: the activation runs in the convolution's epilogue (no pre-activation is kept)
+                return Var(ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
+                                            in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act=act))
             raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                    in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
             gamma = P[norm + ".weight"] if norm else None
