@@ -28,6 +28,8 @@ struct GnArgs {
     int N, HW, C, G, SC;           // SC = slab width (channels)
     int act;
     float eps;
+    float* scratch;                // split path: partial sums of the pixel splits
+    int P, rows_per_split;         // split path: pixel splits per (image, slab) and pixels per split
 };
 
 // NV = vectors a thread keeps in registers when the whole slab fits (NV > 0): the slab is then read from memory
@@ -316,6 +318,251 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
     }
 }
 
+// ---- split path for large images --------------------------------------------------------------------------------
+// One workgroup per (image, slab) walks a 64x64 or 128x128 image alone for hundreds of microseconds while most of the
+// machine idles.  For such slabs the pixels are cut into P splits: a first launch reduces every split to partial sums
+// in a caller-provided scratch buffer, a second launch adds the P partials of its groups / channels in a fixed order
+// (deterministic, no atomics) and applies the result to its own split.  Both launches stream at full width.
+constexpr int GS_T = 256;
+
+__global__ __launch_bounds__(GS_T) void gn_fwd_split_stats_kernel(const GnArgs a) {
+    __shared__ float s_red[(GS_T / 64) * 64 < 128 ? 128 : (GS_T / 64) * 64];
+    const int tid = threadIdx.x;
+    const int slabs = a.C / a.SC;
+    int b = blockIdx.x;
+    const int p = b % a.P; b /= a.P;
+    const int n = b / slabs, c0 = (b - n * slabs) * a.SC;
+    const int vps = a.SC / 8, cv = tid % vps, prow = tid / vps, pstep = GS_T / vps;
+    const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
+    const int cpg = a.C / a.G;
+    const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll 4
+    for (int r = r0 + prow; r < r1; r += pstep) {
+        const bf16x8 v = *(const bf16x8*)(a.x + base + (long long)r * a.C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+    }
+    block_reduce_cols<GS_T>(s, vps, s_red, tid);
+    block_reduce_cols<GS_T>(ss, vps, s_red, tid);
+    __syncthreads();
+    if (tid < vps) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s_red[tid * 8 + j] = s[j]; s_red[64 + tid * 8 + j] = ss[j]; }
+    }
+    __syncthreads();
+    const int ngrp = a.SC / cpg;
+    if (tid < ngrp) {
+        float S = 0.f, SS = 0.f;
+        for (int c = 0; c < cpg; ++c) { S += s_red[tid * cpg + c]; SS += s_red[64 + tid * cpg + c]; }
+        const int g = c0 / cpg + tid;
+        float* o = a.scratch + (((long long)n * a.G + g) * a.P + p) * 2;
+        o[0] = S; o[1] = SS;
+    }
+}
+
+__global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a) {
+    __shared__ float s_mean[32], s_rstd[32];
+    const int tid = threadIdx.x;
+    const int slabs = a.C / a.SC;
+    int b = blockIdx.x;
+    const int p = b % a.P; b /= a.P;
+    const int n = b / slabs, c0 = (b - n * slabs) * a.SC;
+    const int vps = a.SC / 8, cv = tid % vps, prow = tid / vps, pstep = GS_T / vps;
+    const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
+    const int cpg = a.G > 0 ? a.C / a.G : 1;
+    if (a.G > 0) {
+        const int ngrp = a.SC / cpg;
+        if (tid < ngrp) {
+            const int g = c0 / cpg + tid;
+            const float* in = a.scratch + ((long long)n * a.G + g) * a.P * 2;
+            float S = 0.f, SS = 0.f;
+            for (int q = 0; q < a.P; ++q) { S += in[q * 2]; SS += in[q * 2 + 1]; }
+            const float m = 1.0f / (float)(cpg * a.HW);
+            const float mean = S * m;
+            const float rstd = rsqrtf(fmaxf(SS * m - mean * mean, 0.f) + a.eps);
+            s_mean[tid] = mean; s_rstd[tid] = rstd;
+            if (p == 0 && a.stats) {
+                a.stats[((long long)n * a.G + g) * 2 + 0] = mean;
+                a.stats[((long long)n * a.G + g) * 2 + 1] = rstd;
+            }
+        }
+        __syncthreads();
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (a.G > 0) {
+            const int cl = cv * 8 + j, g = cl / cpg;
+            const float ga = a.gamma[c0 + cl] * s_rstd[g];
+            sc[j] = ga; sh[j] = a.beta[c0 + cl] - s_mean[g] * ga;
+        } else {
+            sc[j] = 1.f; sh[j] = 0.f;
+        }
+    }
+    const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
+#pragma unroll 2
+    for (int r = r0 + prow; r < r1; r += pstep) {
+        const long long e = base + (long long)r * a.C;
+        const bf16x8 v = *(const bf16x8*)(a.x + e);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act);
+        if (a.mask) {
+            const unsigned m = a.mask[e >> 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (m >> j) & 1 ? o[j] * a.mask_scale : 0.f;
+        }
+        if (a.res) {
+            const bf16x8 rv = *(const bf16x8*)(a.res + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += (float)rv[j];
+        }
+        bf16x8 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (bf16)o[j];
+        *(bf16x8*)(a.y + e) = w;
+    }
+}
+
+// g = dy * mask * act'(z) and xhat of one vector (shared by the two backward split kernels)
+struct GnBwdLane {
+    float ga[8], be[8], mean[8], rstd[8];
+};
+__device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, GnBwdLane& L) {
+    const int cpg = a.G > 0 ? a.C / a.G : 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (a.G > 0) {
+            const int g = (c + j) / cpg;
+            L.ga[j] = a.gamma[c + j]; L.be[j] = a.beta[c + j];
+            L.mean[j] = a.stats[((long long)n * a.G + g) * 2 + 0];
+            L.rstd[j] = a.stats[((long long)n * a.G + g) * 2 + 1];
+        } else {
+            L.ga[j] = 1.f; L.be[j] = 0.f; L.mean[j] = 0.f; L.rstd[j] = 1.f;
+        }
+    }
+}
+__device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, long long e, float (&g)[8], float (&xh)[8], float (&xf)[8]) {
+    const bf16x8 xv = *(const bf16x8*)(a.x + e), dv = *(const bf16x8*)(a.dy + e);
+    const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+    const float ms = a.mask ? a.mask_scale : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        xf[j] = (float)xv[j];
+        xh[j] = (xf[j] - L.mean[j]) * L.rstd[j];
+        const float gg = (float)dv[j] * act_bwd(xh[j] * L.ga[j] + L.be[j], a.act) * ms;
+        g[j] = (m >> j) & 1 ? gg : 0.f;
+    }
+}
+
+// scratch layout (backward): [N][P][3][C] = per split and channel: sum g, sum g*xhat, sum x
+__global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a) {
+    __shared__ float s_red[(GS_T / 64) * 64 < 128 ? 128 : (GS_T / 64) * 64];
+    const int tid = threadIdx.x;
+    const int slabs = a.C / a.SC;
+    int b = blockIdx.x;
+    const int p = b % a.P; b /= a.P;
+    const int n = b / slabs, c0 = (b - n * slabs) * a.SC;
+    const int vps = a.SC / 8, cv = tid % vps, prow = tid / vps, pstep = GS_T / vps;
+    const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
+    GnBwdLane L;
+    gn_bwd_lane_init(a, n, c0 + cv * 8, L);
+    float a1[8], a2[8], sx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = sx[j] = 0.f;
+    const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
+#pragma unroll 2
+    for (int r = r0 + prow; r < r1; r += pstep) {
+        float g[8], xh[8], xf[8];
+        gn_bwd_gx(a, L, base + (long long)r * a.C, g, xh, xf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
+    }
+    block_reduce_cols<GS_T>(a1, vps, s_red, tid);
+    block_reduce_cols<GS_T>(a2, vps, s_red, tid);
+    block_reduce_cols<GS_T>(sx, vps, s_red, tid);
+    if (tid < vps) {
+        float* o = a.scratch + (((long long)n * a.P + p) * 3) * a.C + c0 + tid * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = a1[j]; o[a.C + j] = a2[j]; o[2 * a.C + j] = sx[j]; }
+    }
+}
+
+__global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a) {
+    __shared__ float s_a1[64], s_a2[64], s_sx[64], s_s1[32], s_s2[32];
+    const int tid = threadIdx.x;
+    const int slabs = a.C / a.SC;
+    int b = blockIdx.x;
+    const int p = b % a.P; b /= a.P;
+    const int n = b / slabs, c0 = (b - n * slabs) * a.SC;
+    const int vps = a.SC / 8, cv = tid % vps, prow = tid / vps, pstep = GS_T / vps;
+    const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
+    const int cpg = a.G > 0 ? a.C / a.G : 1;
+    if (tid < a.SC) {                                 // per-channel totals: the P partials in a fixed order
+        const float* in = a.scratch + ((long long)n * a.P * 3) * a.C + c0 + tid;
+        float u = 0.f, v = 0.f, w = 0.f;
+        for (int q = 0; q < a.P; ++q) { u += in[(q * 3 + 0) * a.C]; v += in[(q * 3 + 1) * a.C]; w += in[(q * 3 + 2) * a.C]; }
+        s_a1[tid] = u; s_a2[tid] = v; s_sx[tid] = w;
+    }
+    __syncthreads();
+    if (a.G > 0) {
+        const int ngrp = a.SC / cpg;
+        if (tid < ngrp) {
+            float u = 0.f, v = 0.f;
+            for (int c = 0; c < cpg; ++c) {
+                const float ga = a.gamma[c0 + tid * cpg + c];
+                u += s_a1[tid * cpg + c] * ga; v += s_a2[tid * cpg + c] * ga;
+            }
+            const float im = 1.0f / (float)(cpg * a.HW);
+            s_s1[tid] = u * im; s_s2[tid] = v * im;
+        }
+        __syncthreads();
+    }
+    if (p == 0 && tid < a.SC) {                       // per-image parameter-gradient partial sums
+        const int c = c0 + tid;
+        float dbias = s_a1[tid];
+        if (a.G > 0) {
+            const int g = c / cpg, gl = tid / cpg;
+            const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
+            a.part[((long long)n * 3 + 0) * a.C + c] = s_a2[tid];
+            a.part[((long long)n * 3 + 1) * a.C + c] = s_a1[tid];
+            // sum over pixels of dx_c = rstd (gamma_c g - S1 - xhat S2), with sum xhat_c = rstd (sum x_c - HW mean)
+            dbias = rstd * (a.gamma[c] * s_a1[tid] - (float)a.HW * s_s1[gl] - s_s2[gl] * rstd * (s_sx[tid] - (float)a.HW * mean));
+        }
+        a.part[((long long)n * 3 + 2) * a.C + c] = dbias;
+    }
+    GnBwdLane L;
+    gn_bwd_lane_init(a, n, c0 + cv * 8, L);
+    float S1[8], S2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (cv * 8 + j) / cpg;
+        S1[j] = a.G > 0 ? s_s1[g] : 0.f; S2[j] = a.G > 0 ? s_s2[g] : 0.f;
+    }
+    const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
+#pragma unroll 2
+    for (int r = r0 + prow; r < r1; r += pstep) {
+        const long long e = base + (long long)r * a.C;
+        float g[8], xh[8], xf[8];
+        gn_bwd_gx(a, L, e, g, xh, xf);
+        bf16x8 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (bf16)(L.rstd[j] * (L.ga[j] * g[j] - (S1[j] + xh[j] * S2[j])));
+        *(bf16x8*)(a.y + e) = w;
+    }
+}
+
+// splits of a slab's pixels on the split path (0 = the slab is small enough for one workgroup)
+static int gn_splits(const GnArgs& a) {
+    const long long vecs = (long long)a.HW * (a.SC / 8);
+    if (vecs <= 4096) return 0;
+    long long p = (vecs + 2047) / 2048;
+    return (int)(p > 64 ? 64 : p);
+}
+
 static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     DDPM_REQUIRE(d && d->x && d->y, "%s: null pointer", what);
     DDPM_REQUIRE(d->N > 0 && d->HW > 0 && d->C > 0 && d->C % 8 == 0, "%s: C (%d) must be a positive multiple of 8", what, d->C);
@@ -345,7 +592,37 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     a.mask_scale = d->mask_scale; a.y = (bf16*)d->y; a.stats = d->stats; a.dy = (const bf16*)d->dy; a.part = d->part;
     a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.SC = sc; a.act = d->act;
     a.eps = d->eps;
+    a.scratch = d->scratch; a.P = 0; a.rows_per_split = 0;
     return DDPM_OK;
+}
+
+// floats of scratch the split path needs for this problem (0: the single-workgroup path is used)
+static long long gn_scratch_need(const GnArgs& a, bool backward) {
+    const int P = gn_splits(a);
+    if (!P) return 0;
+    return backward ? (long long)a.N * P * 3 * a.C : (long long)a.N * (a.G > 0 ? a.G : 0) * P * 2;
+}
+
+extern "C" int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward) {
+    GnArgs a;
+    ddpm_gn_desc t = *d;
+    if (!t.x) t.x = (const void*)16;                  // sizing query: pointers are not dereferenced
+    if (!t.y) t.y = (void*)16;
+    if (t.G > 0) { if (!t.gamma) t.gamma = (const float*)16; if (!t.beta) t.beta = (const float*)16; if (!t.stats) t.stats = (float*)16; }
+    if (gn_prepare(a, &t, "gn_scratch_floats")) return -1;
+    const long long need = gn_scratch_need(a, backward != 0);
+    return need > 0 ? need : (gn_splits(a) ? 1 : 0);   // activation-only forward needs no partial sums but still takes the split path
+}
+
+// true when the split path runs (enough scratch was given)
+static bool gn_use_split(GnArgs& a, const ddpm_gn_desc* d, bool backward) {
+    const int P = gn_splits(a);
+    if (!P) return false;
+    const long long need = gn_scratch_need(a, backward);
+    if (need > 0 && (!d->scratch || d->scratch_floats < need)) return false;
+    a.P = P;
+    a.rows_per_split = (a.HW + P - 1) / P;
+    return true;
 }
 
 // Workgroup size / vectors per thread: aim for 2 vectors per thread (more waves, still two loads in flight each);
@@ -365,6 +642,12 @@ extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_)
     hipStream_t stream = (hipStream_t)stream_;
     GnArgs a;
     if (int rc = gn_prepare(a, d, "gn_forward")) return rc;
+    if (gn_use_split(a, d, false)) {
+        const int units = a.N * (a.C / a.SC) * a.P;
+        if (a.G > 0) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        hipLaunchKernelGGL(gn_fwd_split_apply_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        return ddpm_check_launch("gn_forward");
+    }
     GN_DISPATCH(gn_fwd_kernel)
     return ddpm_check_launch("gn_forward");
 }
@@ -375,6 +658,12 @@ extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_
     if (int rc = gn_prepare(a, d, "gn_backward")) return rc;
     DDPM_REQUIRE(d->dy, "gn_backward: null dy");
     DDPM_REQUIRE(a.part, "gn_backward: partial-sum workspace required");
+    if (gn_use_split(a, d, true)) {
+        const int units = a.N * (a.C / a.SC) * a.P;
+        hipLaunchKernelGGL(gn_bwd_split_sums_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        hipLaunchKernelGGL(gn_bwd_split_apply_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        return ddpm_check_launch("gn_backward");
+    }
     GN_DISPATCH(gn_bwd_kernel)
     return ddpm_check_launch("gn_backward");
 }

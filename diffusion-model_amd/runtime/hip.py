@@ -36,7 +36,7 @@ class GnDesc(C.Structure):
     _fields_ = [
         ("x", _vp), ("gamma", _vp), ("beta", _vp), ("res", _vp), ("mask", _vp), ("mask_scale", _f),
         ("y", _vp), ("stats", _vp), ("dy", _vp), ("part", _vp),
-        ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f),
+        ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f), ("scratch", _vp), ("scratch_floats", _i64),
     ]
 
 
@@ -111,6 +111,7 @@ _PROTOS = {
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
+    "ddpm_gn_scratch_floats": ([C.POINTER(GnDesc), _i], _i64),
     "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),

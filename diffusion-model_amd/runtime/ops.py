@@ -127,6 +127,18 @@ def conv_wgrad(kind: int, x0: Tensor, dy: Tensor, cout: int, dw: Optional[Tensor
     return dw
 
 
+def _gn_scratch(d, backward: int, device) -> Optional[Tensor]:
+    """workspace for the many-workgroup path of large images (None when the shape runs on one workgroup per slab)"""
+    need = hip.lib().ddpm_gn_scratch_floats(C.byref(d), backward)
+    if need < 0:
+        raise RuntimeError(hip.lib().ddpm_last_error().decode())
+    if need == 0:
+        return None
+    t = torch.empty(need, device=device, dtype=torch.float32)
+    d.scratch, d.scratch_floats = t.data_ptr(), need
+    return t
+
+
 def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int, *,
                    res: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
                    stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5):
@@ -140,7 +152,8 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=None, part=None, N=n, HW=h * w, C=c, G=groups,
                    act=act, eps=eps)
-    _launch("gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
+    scratch = _gn_scratch(d, 0, x.device)
+    _launch("gn_fwd_split_kernel" if scratch is not None else "gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream()))
     return out, stats
 
@@ -157,7 +170,8 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=None, mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), part=hip.ptr(part), N=n, HW=h * w, C=c, G=groups, act=act,
                    eps=eps)
-    _launch("gn_bwd_kernel", lambda: (_nb(x, dy, mask, out, gamma, beta, stats, part), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
+    scratch = _gn_scratch(d, 1, x.device)
+    _launch("gn_bwd_split_kernel" if scratch is not None else "gn_bwd_kernel", lambda: (_nb(x, dy, mask, out, gamma, beta, stats, part), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream()))
     return out
 

@@ -126,6 +126,10 @@ typedef struct ddpm_gn_desc {
     int N, HW, C, G;          /* G = 0: no normalisation, activation only */
     int act;
     float eps;
+    float* scratch;           /* optional workspace of scratch_floats floats (ddpm_gn_scratch_floats): with it, images too large
+                               * for one workgroup per (image, channel slab) are processed by many workgroups in two launches
+                               * (partial sums, then apply); without it one workgroup walks the slab */
+    int64_t scratch_floats;
 } ddpm_gn_desc;
 
 /* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:
@@ -133,6 +137,8 @@ typedef struct ddpm_gn_desc {
 int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream);
 /* dx and the per-image partial sums of dgamma, dbeta, dbias of the above (no atomics: deterministic). */
 int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
+/* floats of `scratch` the forward (backward = 0) or backward (1) call would use for this shape; 0 = none; -1 on error */
+int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward);
 
 /* ---- depthwise 3x3 convolution, stride 1, padding 1, NHWC bf16 (dwconv.hip) ---------------------- */
 

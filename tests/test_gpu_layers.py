@@ -20,6 +20,8 @@ def bits(k):
                                           (5, 512, 2, 32, "gelu"), (2, 256, 2, 16, "none"), (2, 64, 32, 16, "gelu"),
                                           (2, 64, 8, 16, "selu"), (2, 32, 8, 16, "leaky_relu"), (2, 32, 8, 16, "relu6"), (2, 64, 4, 16, "hardsigmoid"),
                                           (2, 64, 4, 16, "relu"), (2, 64, 4, 16, "tanh"), (2, 64, 4, 16, "sigmoid"),
+                                          # large images: the many-workgroup (split) path, ragged split sizes, activation-only
+                                          (1, 32, 64, 16, "gelu"), (2, 64, 48, 16, "silu"), (2, 64, 40, 0, "gelu"), (1, 128, 128, 16, "gelu"),
                                           (2, 32, 8, 0, "gelu")])
 def test_groupnorm_act_fwd_bwd(dev, n, c, h, g, act):
     x = r16(hash_normal((n, c, h, h), 1) * 1.5 + 0.7)
