@@ -33,10 +33,10 @@ struct ConvArgs {
 // Loads are issued in batches of STAGE_U per thread before any of them is consumed, so that each thread keeps
 // several 16-byte requests in flight (the tensors are mostly L2 / Infinity-Cache resident: latency, not bandwidth,
 // is what a one-load-at-a-time loop would pay).
-#define STAGE_U 8
+#define STAGE_U 4
 
 template <int WM, int WN, int NT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int T = 256, BM = 32 * WM, BNW = 32 * NT, BN = BNW * WN;
     constexpr int OS = BN * 2 + 16;   // epilogue LDS row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
