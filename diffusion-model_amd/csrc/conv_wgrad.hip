@@ -38,7 +38,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-#define WG_U 6
+#define WG_U 4
 
 template <int NCO, int MAXI>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz, const int gx, char* smem) {
@@ -216,7 +216,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
 }
 
 template <int NCO, int MAXI>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wgrad_body<NCO, MAXI>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, smem);
 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // of a network's can run together at its end, filling the machine instead of paying a latency-bound launch each.
 // tab: the problems of this kernel variant; first[p] = first flat workgroup of problem p (first[n] = total).
 template <int NCO, int MAXI>
-__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WgradArgs* __restrict__ tab, const int* __restrict__ first, const int n) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_group_kernel(const WgradArgs* __restrict__ tab, const int* __restrict__ first, const int n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
     int lo = 0, hi = n;
