@@ -65,8 +65,19 @@ def cpu_baseline(channels, size, batch, steps):
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
+    # sampling: a few steps of the ancestral chain, extrapolated to the full T = 120 steps
+    with torch.no_grad():
+        frozen = {k: v.detach() for k, v in p.items()}
+        x = torch.randn(batch, channels, size, size)
+        ssteps = 4
+        xs = O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x) for _ in range(ssteps)], steps=1)
+        t1 = time.perf_counter()
+        xs = O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x) for _ in range(ssteps)], steps=ssteps)
+        ds = (time.perf_counter() - t1) / ssteps
     return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of batch {batch} at {size}x{size}x{channels} (oracle/ref_cpu.py, fp32, dropout on, Adam)"}
+            "sample": f"{steps} train steps of batch {batch} at {size}x{size}x{channels} (oracle/ref_cpu.py, fp32, dropout on, Adam)",
+            "sampling": {"value": batch / (120 * ds), "unit": "images/s",
+                         "sample": f"{ssteps} sampling steps of batch {batch}, extrapolated to the 120-step chain"}}
 
 
 def main():

@@ -1,1 +1,1 @@
-from .optimizer import OPTIMIZERS, FusedAdam  # noqa: F401
+from .optimizer import OPTIMIZERS, FusedAdam, load_checkpoint, save_checkpoint  # noqa: F401

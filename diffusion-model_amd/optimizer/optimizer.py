@@ -95,6 +95,70 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
+    # ---- checkpoint interchange ----------------------------------------------------------------------------------------
+    # The reference saves optimizer.state_dict() of torch.optim.Adam into its checkpoints (base_trainer.py:118-130,285-294
+    # there).  The flat moment buffers are exposed in exactly that schema (per-parameter 'step', 'exp_avg', 'exp_avg_sq'),
+    # so a checkpoint written here resumes under torch.optim.Adam and one written there resumes here.
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._flat is None:
+            return sd
+        ps = self._params()
+        step = self._step.to(torch.float32).reshape(()).clone()
+        sd["state"] = {i: {"step": step.clone(), "exp_avg": self._m[o:o + p.numel()].view(p.shape).clone(),
+                           "exp_avg_sq": self._v[o:o + p.numel()].view(p.shape).clone()}
+                       for i, (p, o) in enumerate(zip(ps, self._offs))}
+        if self._ema is not None:
+            sd["ema"] = [e.clone() for e in self.ema_parameters()]
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        state = state_dict.get("state", {})
+        ema = state_dict.get("ema")
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        if not state:
+            return
+        if self._flat is None:
+            self._flatten()
+        ps = self._params()
+        steps = []
+        for i, (p, o) in enumerate(zip(ps, self._offs)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            self._m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self._v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.append(int(float(st["step"])))
+        if steps:
+            if len(set(steps)) != 1:
+                raise ValueError("FusedAdam keeps one step counter: the checkpoint's parameters are at different steps")
+            self._step.fill_(steps[0])
+        self._lr.fill_(float(self.param_groups[0]["lr"]))
+        if ema is not None and self._ema is not None:
+            for dst, src in zip(self.ema_parameters(), ema):
+                dst.copy_(src)
+
+
+def save_checkpoint(path: str, epoch: int, model, optimizer, lr_scheduler=None) -> None:
+    """Write a checkpoint in the reference's schema (base_trainer.py:118-130 there)."""
+    torch.save({"num_epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                "lr_scheduler_state_dict": lr_scheduler.state_dict() if lr_scheduler is not None else None}, path)
+
+
+def load_checkpoint(path: str, model, optimizer=None, lr_scheduler=None, map_location=None) -> int:
+    """Resume from a checkpoint in the reference's schema (the reference only ever saves; base_trainer.py:40 has an unused
+    start_epoch).  Returns the stored epoch.  Loaded with weights_only=True: nothing in the file is executed."""
+    ck = torch.load(path, map_location=map_location, weights_only=True)
+    model.load_state_dict(ck["model_state_dict"])
+    if optimizer is not None and ck.get("optimizer_state_dict") is not None:
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+    if lr_scheduler is not None and ck.get("lr_scheduler_state_dict") is not None:
+        lr_scheduler.load_state_dict(ck["lr_scheduler_state_dict"])
+    bump_weight_epoch()
+    return int(ck["num_epoch"])
+
+
 OPTIMIZERS = {
     "adam": torch.optim.Adam,
     "adamw": torch.optim.AdamW,

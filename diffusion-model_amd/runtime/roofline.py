@@ -83,6 +83,12 @@ def measure(step: Callable[[], None], reps: int = 3, traffic_file: str = "", det
         out = {"bound": "hbm", "achieved": t["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
     else:
         out = {"bound": "mfma", "achieved": t["TFLOP/s"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_frac}
+    # whole step: algorithmic bytes and flops of every launch of one step over the time the launches took back to back
+    tot_sec = sum(v[1] for v in acc.values()) / reps
+    tot_b = sum(v[2] for v in acc.values()) / reps
+    tot_f = sum(v[3] for v in acc.values()) / reps
+    out["step"] = {"algorithmic_GB": tot_b * 1e-9, "GFLOP": tot_f * 1e-9, "kernel_ms": tot_sec * 1e3,
+                   "hbm_frac": tot_b / tot_sec * 1e-9 / HBM_PEAK_GBS, "mfma_frac": tot_f / tot_sec * 1e-12 / MFMA_BF16_PEAK_TFLOPS}
     out.update({"traffic": traffic, "kernel": top, "launches_per_step": t["launches_per_step"], "avg_us": t["avg_us"],
                 "algorithmic_bytes_per_launch": t["bytes_per_launch"],
                 "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items() if kk != "bytes_per_launch"} for k, v in table.items()}})

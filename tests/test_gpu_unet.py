@@ -465,3 +465,57 @@ def test_graphed_and_concurrent_samplers_follow_the_reference_chain(golden, dev)
     torch.cuda.synchronize()
     assert out.shape == (4, 1, 32, 32) and torch.isfinite(out).all() and out.abs().max() < 3.0
     assert not torch.equal(out[:2], out[2:])                         # the two chains draw different noise
+
+
+def test_checkpoint_interchange_and_resume(dev, tmp_path):
+    """Checkpoints in the reference's schema (num_epoch / model_state_dict / optimizer_state_dict / lr_scheduler_state_dict,
+    base_trainer.py:118-130 there): FusedAdam's state is readable by torch.optim.Adam and the other way round, and a run
+    resumed from a checkpoint continues exactly like the uninterrupted one."""
+    from dm_amd.optimizer import FusedAdam, load_checkpoint, save_checkpoint
+    crit = ELBOLoss("mse")
+    x0 = (hash_uniform((4, 3, 32, 32), 5) * 2 - 1).to(dev)
+
+    def steps(m, opt, its):
+        for it in its:
+            t = torch.tensor([3, 40, 80, 120], device=dev)
+            noise = hash_normal((4, 3, 32, 32), 50 + it).to(dev)
+            opt.zero_grad(set_to_none=True)
+            crit(m, t, m(m.q(x0, t, noise=noise), t), x0)["Loss"].backward()
+            opt.step()
+
+    ma, _, _ = build(dev, 3, "gelu"); ma.eval()
+    oa = FusedAdam(ma.parameters(), lr=1e-3)
+    steps(ma, oa, range(4))                                   # uninterrupted
+
+    mb, _, _ = build(dev, 3, "gelu"); mb.eval()
+    ob = FusedAdam(mb.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ob, T_max=10, eta_min=5e-4)
+    steps(mb, ob, range(2))
+    path = str(tmp_path / "ddpm_last.pth")
+    save_checkpoint(path, 7, mb, ob, sched)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"num_epoch", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict"}
+    assert len(ck["model_state_dict"]) == 350 and set(ck["optimizer_state_dict"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+    mc, _, _ = build(dev, 3, "gelu", seed=9); mc.eval()       # different weights, then resumed
+    oc = FusedAdam(mc.parameters(), lr=1e-3)
+    assert load_checkpoint(path, mc, oc, map_location=dev) == 7
+    steps(mc, oc, range(2, 4))
+    # (a handful of weight-gradient sums use fp32 atomics, so two runs differ by summation order; Adam turns that into ~1e-3)
+    for (k, pa), pc in zip(ma.named_parameters(), mc.parameters()):
+        assert l2_err(pc.detach().cpu(), pa.detach().cpu()) < 4e-3, k
+
+    # torch.optim.Adam resumes from the same file and takes the same step
+    md, _, _ = build(dev, 3, "gelu", seed=9); md.eval()
+    od = torch.optim.Adam(md.parameters(), lr=1e-3)
+    load_checkpoint(path, md, od, map_location=dev)
+    steps(md, od, range(2, 4))
+    for (k, pa), pd in zip(ma.named_parameters(), md.parameters()):
+        assert l2_err(pd.detach().cpu(), pa.detach().cpu()) < 4e-3, k
+    # ... and FusedAdam reads what torch.optim.Adam wrote
+    me, _, _ = build(dev, 3, "gelu", seed=9); me.eval()
+    oe = FusedAdam(me.parameters(), lr=1e-3)
+    me.load_state_dict(md.state_dict())
+    oe.load_state_dict(od.state_dict())
+    assert int(oe._step.item()) == 4
+    torch.testing.assert_close(oe._m[:100].cpu(), torch.cat([s["exp_avg"].reshape(-1) for s in od.state_dict()["state"].values()])[:100].cpu())
