@@ -459,3 +459,66 @@ extern "C" int ddpm_reduce_rows(const float* src, float* dst, const ddpm_reduce_
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((max_width + 63) / 64, n_entries), dim3(256), 0, stream, src, dst, entries);
     return ddpm_check_launch("reduce_rows");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input pipeline of the reference's dataset loaders on the GPU (datasets/mnist.py:26-39, datasets/flowers102.py:28-38
+// there): transforms.Resize (PIL bilinear: a horizontal then a vertical pass in 22-bit fixed point, each rounded to 8
+// bits) -> ToTensor (/255) -> x*2-1 -> channel replication, plus an optional per-image horizontal flip.  The coefficient
+// tables come from the host (same arithmetic as PIL's precompute_coeffs), so the result is bit-identical to the
+// reference's CPU transforms.  One thread per output pixel (all channels).
+__device__ __forceinline__ int clip8_fixed(int v) {
+    v >>= 22;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void prepare_images_kernel(const unsigned char* __restrict__ src, int N, int H0, int W0, int C0,
+                                                             float* __restrict__ dst, int C, int H, int W,
+                                                             const int* __restrict__ hcoef, const int* __restrict__ hbounds, int hk,
+                                                             const int* __restrict__ vcoef, const int* __restrict__ vbounds, int vk,
+                                                             const unsigned char* __restrict__ flip) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * H * W) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H), n = (int)(idx / ((long long)W * H));
+    const int xs = (flip && flip[n]) ? W - 1 - x : x;          // flipping the output = sampling the mirrored column
+    const unsigned char* img = src + (long long)n * H0 * W0 * C0;
+    const int ymin = vbounds ? vbounds[y * 2] : y, ycnt = vbounds ? vbounds[y * 2 + 1] : 1;
+    const int xmin = hbounds ? hbounds[xs * 2] : xs, xcnt = hbounds ? hbounds[xs * 2 + 1] : 1;
+    for (int c0 = 0; c0 < C0; ++c0) {
+        int acc_v = 1 << 21;
+        int u = 0;
+        for (int j = 0; j < ycnt; ++j) {
+            const unsigned char* row = img + ((long long)(ymin + j) * W0) * C0 + c0;
+            int hval;
+            if (hbounds) {
+                int acc_h = 1 << 21;
+                for (int i = 0; i < xcnt; ++i) acc_h += (int)row[(xmin + i) * C0] * hcoef[xs * hk + i];
+                hval = clip8_fixed(acc_h);
+            } else {
+                hval = row[xmin * C0];
+            }
+            if (vbounds) acc_v += hval * vcoef[y * vk + j];
+            else u = hval;
+        }
+        if (vbounds) u = clip8_fixed(acc_v);
+        const float v = (float)u / 255.0f * 2.0f - 1.0f;
+        if (C0 == C) {
+            dst[(((long long)n * C + c0) * H + y) * W + x] = v;
+        } else {                                               // one source channel replicated (img.expand(3, -1, -1))
+            for (int c = 0; c < C; ++c) dst[(((long long)n * C + c) * H + y) * W + x] = v;
+        }
+    }
+}
+
+extern "C" int ddpm_prepare_images(const uint8_t* src, int N, int H0, int W0, int C0, float* dst, int C, int H, int W, const int32_t* hcoef,
+                                   const int32_t* hbounds, int hk, const int32_t* vcoef, const int32_t* vbounds, int vk, const uint8_t* flip,
+                                   ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(src && dst && N > 0 && H0 > 0 && W0 > 0 && H > 0 && W > 0, "prepare_images: bad arguments");
+    DDPM_REQUIRE(C0 == C || C0 == 1, "prepare_images: %d source channels cannot fill %d output channels", C0, C);
+    DDPM_REQUIRE((hbounds != nullptr) == (hcoef != nullptr) && (vbounds != nullptr) == (vcoef != nullptr), "prepare_images: coefficient tables come in pairs");
+    DDPM_REQUIRE((hbounds || W0 == W) && (vbounds || H0 == H), "prepare_images: sizes differ but no resampling tables were given");
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(prepare_images_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, N, H0, W0, C0, dst, C, H, W,
+                       hcoef, hbounds, hk, vcoef, vbounds, vk, flip);
+    return ddpm_check_launch("prepare_images");
+}

@@ -79,6 +79,15 @@ int ddpm_tanh_bwd_nchw_to_nhwc(const float* dy, const float* y, void* dz, int N,
 /* *seed += odd constant: lets a replayed HIP graph draw fresh randomness every step. */
 int ddpm_bump_seed(uint64_t* seed, ddpm_stream_t stream);
 
+/* Dataset transforms of the reference on the GPU (datasets/mnist.py:26-39, datasets/flowers102.py:28-38, augmentation/
+ * augmentation.py:13): transforms.Resize (PIL bilinear, two fixed-point passes) -> ToTensor -> x*2-1 -> channel
+ * replication (C0 = 1 -> C), optional horizontal flip per image (flip[n] != 0).  src: uint8 [N][H0][W0][C0]; dst: fp32
+ * [N][C][H][W].  hcoef int32 [W][hk] / hbounds int32 [W][2] (first source column, count) and vcoef / vbounds likewise for
+ * rows: PIL's 22-bit fixed-point resampling coefficients, computed by the host; NULL tables = that axis is not resized. */
+int ddpm_prepare_images(const uint8_t* src, int N, int H0, int W0, int C0, float* dst, int C, int H, int W, const int32_t* hcoef,
+                        const int32_t* hbounds, int hk, const int32_t* vcoef, const int32_t* vbounds, int vk, const uint8_t* flip,
+                        ddpm_stream_t stream);
+
 /* ---- dense convolutions on bf16 MFMA (conv_mfma.hip, conv_wgrad.hip) ---------------------------- */
 
 typedef struct ddpm_conv_desc {

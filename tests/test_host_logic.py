@@ -69,3 +69,23 @@ def test_reference_error_conventions():
     with pytest.raises(KeyError):
         dm_ddpm.DDPM(dm_unets.BaseUNet, **dict(YAML, activation="nope"), is_conditional=False, img_channels=1, reconstruction_method="mse",
                      latent_dim=512, device="cpu")
+
+
+def test_pil_resampling_tables_reproduce_pil():
+    """The host-side coefficient tables of the GPU input pipeline, applied with PIL's two-pass fixed-point arithmetic in
+    numpy, equal PIL's own bilinear resize bit for bit."""
+    import numpy as np
+    from PIL import Image
+    from dm_amd.datasets import pil_bilinear_tables
+    rng = np.random.default_rng(1)
+    for h0, w0, h, w in [(28, 28, 32, 32), (48, 48, 32, 32), (97, 61, 64, 64)]:
+        img = rng.integers(0, 256, (h0, w0), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((w, h), Image.BILINEAR))
+        hc, hb, _ = pil_bilinear_tables(w0, w)
+        vc, vb, _ = pil_bilinear_tables(h0, h)
+        t = img.astype(np.int64)
+        t = np.stack([np.clip(((1 << 21) + (t[:, hb[x, 0]:hb[x, 0] + hb[x, 1]] * hc[x, :hb[x, 1]].astype(np.int64)).sum(1)) >> 22, 0, 255)
+                      for x in range(w)], axis=1)
+        t = np.stack([np.clip(((1 << 21) + (t[vb[y, 0]:vb[y, 0] + vb[y, 1]] * vc[y, :vb[y, 1]].astype(np.int64)[:, None]).sum(0)) >> 22, 0, 255)
+                      for y in range(h)], axis=0)
+        assert np.array_equal(t, ref)
