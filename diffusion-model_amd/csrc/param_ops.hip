@@ -14,17 +14,20 @@ __global__ __launch_bounds__(256) void remap_kernel(const ddpm_remap_entry* __re
                                                      int to_a) {
     const int2 ch = chunks[blockIdx.x];
     const ddpm_remap_entry e = entries[ch.x];
-    const long long total = (long long)e.S * e.R * e.K;
-    const long long i0 = (long long)ch.y * REMAP_CHUNK;
+    // one tensor has far fewer than 2^31 elements (checked by the host side when the table is built): 32-bit index
+    // arithmetic, whose divisions cost a fraction of the 64-bit ones
+    const unsigned total = (unsigned)e.S * (unsigned)e.R * (unsigned)e.K;
+    const unsigned i0 = (unsigned)ch.y * REMAP_CHUNK;
+    const unsigned K = (unsigned)e.K, R = (unsigned)e.R;
 #pragma unroll
     for (int u = 0; u < REMAP_CHUNK / 256; ++u) {
-        const long long i = i0 + u * 256 + threadIdx.x;
+        const unsigned i = i0 + u * 256 + threadIdx.x;
         if (i >= total) break;
-        const int k = (int)(i % e.K);
-        const long long sr = i / e.K;
-        const int r = (int)(sr % e.R), s = (int)(sr / e.R);
+        const unsigned sr = i / K;
+        const int k = (int)(i - sr * K);
+        const int s = (int)(sr / R), r = (int)(sr - (unsigned)s * R);
         const bool valid = r < e.Rv && k < e.Kv;
-        const long long bi = (long long)r * e.a_r + (long long)k * e.a_k + e.off_s[s];
+        const int bi = r * e.a_r + k * e.a_k + e.off_s[s];
         if (to_a) {
             const float v = valid ? ((const float*)e.b)[bi] : 0.f;
             if (e.a_bf16) ((bf16*)e.a)[i] = (bf16)v;

@@ -42,6 +42,9 @@ def _entry(a: int, b: int, S, R, K, Rv, Kv, a_r, a_k, off_s: Sequence[int], a_bf
 
 def _to_device(entries: List[hip.RemapEntry], device) -> Tuple[Tensor, Tensor, int]:
     """(entry table, chunk table, number of chunks) on the device"""
+    for e in entries:
+        if e.S * e.R * e.K >= 1 << 31 or e.Rv * e.a_r + e.Kv * e.a_k + max(e.off_s) >= 1 << 31:
+            raise ValueError("a parameter tensor is too large for the remap kernel's 32-bit indices")
     arr = (hip.RemapEntry * len(entries))(*entries)
     t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     ce = hip.lib().ddpm_remap_chunk_elems()
