@@ -15,6 +15,22 @@
 #include "ddpm_hip.h"
 #include "sir_tile.h"
 
+// Diagnostic build only (-DSIR_STAMPS): lane 0 of every wave records the shader clock at phase boundaries into a buffer of
+// its own; no output value depends on it and the product build contains none of this.
+#ifdef SIR_STAMPS
+__device__ unsigned long long* sir_bwd_dbg = nullptr;
+extern "C" int ddpm_sir_bwd_set_dbg(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(sir_bwd_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#define SIRB_STAMP(i)                                                                                      \
+    do {                                                                                                   \
+        if (sir_bwd_dbg && (threadIdx.x & 63) == 0)                                                        \
+            sir_bwd_dbg[((unsigned long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SIRB_STAMP(i)
+#endif
+
 struct SirBwdArgs {
     const bf16* dy;
     const bf16* raw_e; const bf16* raw_d; const bf16* raw_o; const bf16* y_e;
@@ -39,22 +55,33 @@ __device__ __forceinline__ float act_d(float z) {
     else return 1.f;
 }
 
-// Add this thread's per-channel values into the workgroup's [IPW][CS] column table: wave reduction over the lanes that
-// hold other rows of the same channels, then one LDS atomic per channel and wave.
-template <int CH, int M, int CS>
-__device__ __forceinline__ void col_add(const float (&v)[8], int img, int vec, int lane, float* s_tab) {
-    using T = Ew<CH, M>;
-    float r[8];
+// Sum r[0..7] over the R = 64 / VPR lanes of a wave that hold other rows of the same eight channels.  Every exchange
+// halves the set of values a lane keeps (it sends the half its partner keeps), so the whole reduction costs 8 - 8/R
+// shuffles instead of 8 * log2(R).  On return lane (g = lane / VPR, vec = lane % VPR) holds in r[0 .. 8/R) the complete
+// sums of channels vec * 8 + jb + i, with jb the return value.
+template <int VPR>
+__device__ __forceinline__ int fold_cols(float (&r)[8], int lane) {
+    static_assert(VPR >= 1 && VPR <= 64, "a row of vectors fits a wave");
+    // more than eight row groups: plain exchanges over the far ones first (every lane keeps all eight values)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r[j] = v[j];
+    for (int o = 32; o >= VPR * 8; o >>= 1) {
 #pragma unroll
-        for (int o = T::VPR; o < 64; o <<= 1) r[j] += __shfl_xor(r[j], o, 64);
+        for (int j = 0; j < 8; ++j) r[j] += __shfl_xor(r[j], o, 64);
     }
-    if (lane < T::VPR) {
+    constexpr int TOP = VPR * 8 < 64 ? VPR * 8 : 64;
+    int jb = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&s_tab[img * CS + vec * 8 + j], r[j]);
+    for (int o = VPR; o < TOP; o <<= 1) {
+        const int cnt = 4 * VPR / o;
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+            const float lo = r[i], hi = r[i + cnt];
+            r[i] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, o, 64);
+        }
+        if (up) jb += cnt;
     }
+    return jb;
 }
 
 // Deterministic column sums: a thread owns NV consecutive rows, so all rows of a wave belong to one image; the wave
@@ -63,17 +90,13 @@ __device__ __forceinline__ void col_add(const float (&v)[8], int img, int vec, i
 template <int CH, int M, int CS>
 __device__ __forceinline__ void col_store(const float (&v)[8], int wave, int vec, int lane, float* s_slot) {
     using T = Ew<CH, M>;
+    constexpr int KEEP = T::VPR >= 8 ? 8 / (64 / T::VPR) : 1;        // with more than eight row groups lanes hold duplicates: same value, same address
     float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r[j] = v[j];
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+    const int jb = fold_cols<T::VPR>(r, lane);
 #pragma unroll
-        for (int o = T::VPR; o < 64; o <<= 1) r[j] += __shfl_xor(r[j], o, 64);
-    }
-    if (lane < T::VPR) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_slot[wave * CS + vec * 8 + j] = r[j];
-    }
+    for (int i = 0; i < KEEP; ++i) s_slot[wave * CS + vec * 8 + jb + i] = r[i];
 }
 
 template <int IPW, int CS>
@@ -188,16 +211,15 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     float* s_mr = s_grp + IPW * 2 * SIR_G;         // [3][IPW][16][2]  mean, rstd of the three norms
     float* s_p = s_mr + 3 * IPW * 2 * SIR_G;       // per-channel parameters
     constexpr int P_G1 = 0, P_B1 = E, P_G2 = 2 * E, P_B2 = 3 * E, P_WD = 4 * E, P_G3 = 13 * E;
-    float* s_dw = s_p + 13 * E + C;                // [10][E] depthwise tap gradients (rows 0-8) and bias gradient (row 9) of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long n0 = (long long)blockIdx.x * IPW;
     const long long row0 = n0 * HW;
     const int rows_valid = (int)min((long long)M, (a.N - n0) * HW);
     const bool use_mask = a.m_e != nullptr;
 
-    // ---- one round trip for everything small; zero the reduction tables
-    for (int i = tid; i < 9 * E; i += SIR_THREADS) { s_dw[i] = 0.f; s_p[P_WD + i] = a.wdf[i]; }
-    for (int i = tid; i < E; i += SIR_THREADS) s_dw[9 * E + i] = 0.f;
+    SIRB_STAMP(0);
+    // ---- one round trip for everything small
+    for (int i = tid; i < 9 * E; i += SIR_THREADS) s_p[P_WD + i] = a.wdf[i];
     for (int i = tid; i < E; i += SIR_THREADS) {
         s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i]; s_p[P_G2 + i] = a.g2[i]; s_p[P_B2 + i] = a.b2[i];
     }
@@ -241,6 +263,7 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     bf16x8 bfrag1[GemmK<C>::KCH];
     if (wave < MT * (E / 32)) gemm_prefetch<C>(bfrag1, a.wpd + (long long)((wave / MT) * 32 + (lane & 31)) * C, lane);
     __syncthreads();
+    SIRB_STAMP(1);
 
     // ---- last GroupNorm backward (no activation, no dropout): dy -> d_o
     {
@@ -263,6 +286,7 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     }
     __syncthreads();
     col2_flush<C, IPW, E>(s_col, a.part3, n0, a.N, tid);
+    SIRB_STAMP(2);
 
     // ---- projection data-gradient: [M][C] x [E][C]^T -> LDS tile (bf16)
     {
@@ -282,6 +306,7 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     }
     __syncthreads();
 
+    SIRB_STAMP(3);
     // ---- second GroupNorm + activation + dropout backward -> dd (kept in registers as fp32 and in the LDS tile as bf16)
     float g[E1::NV][8];
 #pragma unroll
@@ -311,8 +336,10 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     }
     __syncthreads();
     // table 2 of this norm = depthwise bias gradient: all waves (= all images of the workgroup) folded into row 9
-    for (int c = tid; c < E; c += SIR_THREADS) s_dw[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
+    float* dwp = a.dwpart + (long long)blockIdx.x * 10 * E;
+    for (int c = tid; c < E; c += SIR_THREADS) dwp[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
 
+    SIRB_STAMP(4);
     // ---- depthwise: data-gradient (flipped taps) and weight-gradient share the neighbour reads of dd
     {
         float acc[E1::NV][8];
@@ -348,14 +375,22 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
                     }
                 }
             }
-            col_add<E, M, E>(wg, 0, v1, lane, s_dw + tap * E);
+            // tap gradient of the workgroup: per-wave sums into table (tap & 1) (tables 0 and 1 are idle between the two
+            // norms), then the thread that owns a channel adds the waves in a fixed order.  The barrier of the next
+            // tap separates these reads from the next writes of the same table.
+            float* tab = s_col + (tap & 1) * NWV * E;
+            col_store<E, M, E>(wg, wave, v1, lane, tab);
+            __syncthreads();
+            for (int c = tid; c < E; c += SIR_THREADS) dwp[tap * E + c] = col_total<1, E>(tab, 0, c);
         }
 #pragma unroll
         for (int k = 0; k < E1::NV; ++k)
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[k][j] = (float)(bf16)acc[k][j];     // the unfused path stores this tensor as bf16
     }
+    __syncthreads();                                                          // the last tap's table is read before the next norm refills it
 
+    SIRB_STAMP(5);
     // ---- first GroupNorm + activation + dropout backward -> d_e
     bf16x8 bfrag2[GemmK<E>::KCH];
     if (wave < MT * (C / 32)) gemm_prefetch<E>(bfrag2, a.wed + (long long)((wave / MT) * 32 + (lane & 31)) * E, lane);
@@ -371,9 +406,8 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     }
     __syncthreads();
     col2_flush<E, IPW, E>(s_col, a.part1, n0, a.N, tid);
-    // depthwise tap and bias gradients of this workgroup (complete since the barrier above)
-    for (int i = tid; i < 10 * E; i += SIR_THREADS) a.dwpart[(long long)blockIdx.x * 10 * E + i] = s_dw[i];
 
+    SIRB_STAMP(6);
     // ---- expansion data-gradient: [M][E] x [C][E]^T -> LDS (bf16)
     {
         constexpr int TT = MT * (C / 32);
@@ -392,6 +426,7 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     }
     __syncthreads();
 
+    SIRB_STAMP(7);
     // ---- dropout of the block input and the residual branch: dx = dy + mask * scale * (expansion data-gradient)
 #pragma unroll
     for (int k = 0; k < E3::NV; ++k) {
@@ -407,6 +442,7 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
         }
         *(bf16x8*)(a.dx + (row0 + row) * C + v3 * 8) = o;
     }
+    SIRB_STAMP(8);
 }
 
 
@@ -528,14 +564,12 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
     float* s_mr = s_grp + 2 * SIR_G;               // [3][16][2]
     float* s_p = s_mr + 3 * 2 * SIR_G;
     constexpr int P_G1 = 0, P_B1 = E, P_G2 = 2 * E, P_B2 = 3 * E, P_WD = 4 * E, P_G3 = 13 * E;
-    float* s_dw = s_p + 13 * E + C;                // [10][E]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long n0 = blockIdx.x, row0 = n0 * HW;
     const bool use_mask = a.m_e != nullptr;
 
-    for (int i = tid; i < 9 * E; i += SIR_THREADS) { s_dw[i] = 0.f; s_p[P_WD + i] = a.wdf[i]; }
+    for (int i = tid; i < 9 * E; i += SIR_THREADS) s_p[P_WD + i] = a.wdf[i];
     for (int i = tid; i < E; i += SIR_THREADS) {
-        s_dw[9 * E + i] = 0.f;
         s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i]; s_p[P_G2 + i] = a.g2[i]; s_p[P_B2 + i] = a.b2[i];
     }
     for (int i = tid; i < C; i += SIR_THREADS) s_p[P_G3 + i] = a.g3[i];
@@ -617,11 +651,17 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
     norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_d + row0 * E, use_mask ? a.m_d : nullptr, row0 * E, a.mscale, s_p + P_G2, s_p + P_B2,
                                     s_mr + 2 * SIR_G, s_col, s_grp, a.part2, nullptr, n0, tid);
     __syncthreads();
-    for (int c = tid; c < E; c += SIR_THREADS) s_dw[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
+    float* dwp = a.dwpart + n0 * 10 * E;
+    for (int c = tid; c < E; c += SIR_THREADS) dwp[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
 
     // ---- depthwise data-gradient and weight-gradient, four vectors at a time; the results replace dd in the tile once
     //      every thread has finished reading its neighbours
     bf16x8 dea[E1::NV];
+    static_assert(E1::VPR == 8, "a lane keeps one folded tap sum");
+    float tapsum[9];                               // this lane's share of the wave's tap gradients: channel v1 * 8 + tapj
+    int tapj = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tapsum[t] = 0.f;
 #pragma unroll
     for (int k0 = 0; k0 < E1::NV; k0 += 4) {
         float acc[4][8];
@@ -657,23 +697,36 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
                     }
                 }
             }
-            col_add<E, M, E>(wg, 0, v1, lane, s_dw + tap * E);
+            tapj = fold_cols<E1::VPR>(wg, lane);
+            tapsum[tap] += wg[0];
+            asm volatile("" : "+v"(tapsum[tap]));          // (with the one below) pins the order of evaluation: left alone the scheduler interleaves the chunks and spills
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int j = 0; j < 8; ++j) dea[k0 + k][j] = (bf16)acc[k][j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(dea[k0 + k]));    // convert now: the fp32 accumulators of a finished chunk are dead
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) *(bf16x8*)(s_e + (r1 * E1::NV + k) * ES + v1 * 16) = dea[k];
+    // tap gradients of the workgroup, three taps per round through the three (now idle) column tables: per-wave sums,
+    // then the thread that owns (tap, channel) adds the waves in a fixed order
+#pragma unroll
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) s_col[(t * NWV + wave) * E + v1 * 8 + tapj] = tapsum[t0 + t];
+        __syncthreads();
+        if (tid < 3 * E) dwp[t0 * E + tid] = col_total<1, E>(s_col + (tid / E) * NWV * E, 0, tid % E);
+        __syncthreads();
+    }
 
     // ---- first GroupNorm + activation + dropout backward -> d_e (tile + global); own elements only, no barrier needed before
     norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_e + row0 * E, use_mask ? a.m_e : nullptr, row0 * E, a.mscale, s_p + P_G1, s_p + P_B1, s_mr,
                                     s_col, s_grp, a.part1, a.d_e + row0 * E, n0, tid);
     __syncthreads();
     col2_flush<E, 1, E>(s_col, a.part1, n0, a.N, tid);
-    for (int i = tid; i < 10 * E; i += SIR_THREADS) a.dwpart[n0 * 10 * E + i] = s_dw[i];
 
     // ---- expansion data-gradient (accumulators across a barrier, then the [M][C] view of the tile)
     {
@@ -735,7 +788,7 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_bwd_big_kernel(const SirBwdAr
 template <int C, int W>
 static int sir_bwd_big_launch(const SirBwdArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, M = W * W;
-    constexpr int lds = M * (E * 2 + 16) + (3 * (SIR_THREADS / 64) * E + 2 * SIR_G + 3 * 2 * SIR_G + 13 * E + C + 10 * E) * 4;
+    constexpr int lds = M * (E * 2 + 16) + (3 * (SIR_THREADS / 64) * E + 2 * SIR_G + 3 * 2 * SIR_G + 13 * E + C) * 4;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     auto k = sir_bwd_big_kernel<C, W>;
     static bool attr_set = false;
@@ -764,7 +817,7 @@ template <int C, int W>
 static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
     constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) +
-                        (3 * (SIR_THREADS / 64) * E + IPW * 2 * SIR_G + 3 * IPW * 2 * SIR_G + 13 * E + C + 10 * E) * 4;
+                        (3 * (SIR_THREADS / 64) * E + IPW * 2 * SIR_G + 3 * IPW * 2 * SIR_G + 13 * E + C) * 4;
     static_assert(lds <= 160 * 1024, "tiles do not fit LDS");
     auto k = sir_bwd_kernel<C, W>;
     static bool attr_set = false;
