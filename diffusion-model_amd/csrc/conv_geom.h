@@ -50,7 +50,19 @@ struct ConvGeom {
     int tap_slice[CONV_MAX_TAPS];   // which [rows][Cin] weight slice the tap multiplies with
     int max_taps;                   // largest tap count of any class
     int nslices;
+    int tw_shift, thw_shift;        // TW and TH*TW are powers of two
+    unsigned pw_magic, phw_magic;   // x / PW = (x * pw_magic) >> 32 for x < 65536 (same for PH*PW): integer division costs ~40 instructions
 };
+
+static inline int ilog2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+static inline unsigned div_magic(int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }   // 0: divisor 1
+#if defined(__HIPCC__)
+__device__ __forceinline__ int div_fast(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
+#endif
 
 static inline int next_pow2(int v) {
     int p = 1;
@@ -140,5 +152,8 @@ static inline int conv_geom_init(ConvGeom* g, int kind, int N, int IH, int IW, i
     g->PW = (tw - 1) * g->SI + (dmax_w - g->dmin_w) + 1;
     g->tiles_h = (g->GH + th - 1) / th; g->tiles_w = (g->GW + tw - 1) / tw; g->tiles_n = (N + g->NB - 1) / g->NB;
     for (int j = 0; j < nt; ++j) g->tap_poff[j] = dh[j] * g->PW + dw[j];   // dh/dw are patch-relative (>= 0)
+    g->tw_shift = ilog2_exact(tw); g->thw_shift = ilog2_exact(tw * th);
+    g->pw_magic = div_magic(g->PW); g->phw_magic = div_magic(g->PH * g->PW);
+    if (g->NB * g->PH * g->PW >= 65536) return -1;                          // range of the multiply-high division
     return 0;
 }

@@ -35,8 +35,23 @@ struct ConvArgs {
 // is what a one-load-at-a-time loop would pay).
 #define STAGE_U 4
 
+// Diagnostic build only (-DCONV_STAMPS): lane 0 of every wave records the shader clock at phase boundaries.
+#ifdef CONV_STAMPS
+__device__ unsigned long long* conv_dbg = nullptr;
+extern "C" int ddpm_conv_set_dbg(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(conv_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#define CONV_STAMP(i)                                                                                                        \
+    do {                                                                                                                     \
+        if (conv_dbg && (threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0)                                       \
+            conv_dbg[((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CONV_STAMP(i)
+#endif
+
 template <int WM, int WN, int NT>
-__global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int T = 256, BM = 32 * WM, BNW = 32 * NT, BN = BNW * WN;
     constexpr int OS = BN * 2 + 16;   // epilogue LDS row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,24 +70,30 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
     const int PHW = g.PH * g.PW, npix = g.NB * PHW;
     const int Cin = a.C0 + a.C1;
 
+    CONV_STAMP(0);
     int* s_pl = (int*)smem;                                      // pixel linear index (or -1) per patch pixel
-    char* s_patch = smem + ((npix * 4 + 15) & ~15);
+    int* s_tap = (int*)(smem + ((npix * 4 + 15) & ~15));         // [16] weight slice of each tap of this class
+    char* s_patch = (char*)(s_tap + CONV_MAX_TAPS);
     char* s_w = s_patch + npix * CONV_RS;
 
     // ---- patch pixel table: patch slot -> linear input pixel (n*IH + iy)*IW + ix, or -1 if padding
     for (int p = tid; p < npix; p += T) {
-        const int il = p / PHW, r = p - il * PHW;
-        const int py = r / g.PW, px = r - py * g.PW;
+        const int il = div_fast(p, g.phw_magic), r = p - il * PHW;
+        const int py = div_fast(r, g.pw_magic), px = r - py * g.PW;
         const int n = n0 + il, iy = oy * g.SI + g.dmin_h + py, ix = ox * g.SI + g.dmin_w + px;
         const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
         s_pl[p] = ok ? (n * g.IH + iy) * g.IW + ix : -1;
     }
+    // tap tables: the weight slices go to LDS (looked up per staged weight row), the patch offsets stay in a register,
+    // lane j holding tap j's (the MFMA loop reads them with v_readlane: a scalar load per tap would sit on its critical path)
+    if (tid < CONV_MAX_TAPS) s_tap[tid] = tid < ntaps ? g.tap_slice[tap0 + tid] : 0;
+    const int my_poff = lane < ntaps ? g.tap_poff[tap0 + lane] : 0;
 
     // ---- this lane's A row (position) -> byte offset of its pixel inside the patch
     const int thw = g.TH * g.TW;
     const int pidx = wave * 32 + (lane & 31);
-    const int il = pidx / thw, rem = pidx - il * thw;
-    const int ty = rem / g.TW, tx = rem - ty * g.TW;
+    const int il = pidx >> g.thw_shift, rem = pidx - (il << g.thw_shift);
+    const int ty = rem >> g.tw_shift, tx = rem - (ty << g.tw_shift);
     const int a_base = (il * PHW + ty * g.SI * g.PW + tx * g.SI) * CONV_RS + (lane >> 5) * 16;
     const int b_base = (wave_n * BNW + (lane & 31)) * CONV_RS + (lane >> 5) * 16;
 
@@ -86,88 +107,105 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     }
 
-    const int ihw = g.IH * g.IW;
     for (int c0 = 0; c0 < Cin; c0 += CONV_CK) {
         const int parts = (Cin - c0 >= CONV_CK) ? 4 : (Cin - c0) / 8;   // 16-byte pieces per row in this chunk
         const int ksteps = (parts + 1) / 2;
         __syncthreads();   // previous chunk fully consumed (and s_pl visible on the first trip)
+        if (c0 == 0) CONV_STAMP(1);
         // -- stage the patch AND the weight rows of this chunk in one batched round: every thread first issues all of
         //    its global loads (up to STAGE_U x 16 B), then applies the fused input transforms and writes LDS.
         const bool src1 = c0 >= a.C0;
         const bf16* src = src1 ? a.in1 : a.in0;
         const int cs = src1 ? a.C1 : a.C0, cc = src1 ? c0 - a.C0 : c0;
         const bool xform = !src1 && (a.in_add || a.in_mask);
-        const int n_patch = npix * 4, n_items = n_patch + ntaps * BN * 4;
-        for (int base = tid; base < n_items; base += T * STAGE_U) {
-            bf16x8 v[STAGE_U];
-            long long e[STAGE_U];
-            int pl[STAGE_U], ldst[STAGE_U];
-#pragma unroll
-            for (int u = 0; u < STAGE_U; ++u) {
-                const int it = base + u * T;
-                pl[u] = -1; ldst[u] = -1; e[u] = 0;
-                if (it < n_patch) {
-                    const int p = it >> 2, part = it & 3;
-                    if (part < parts) {
-                        pl[u] = s_pl[p];
-                        ldst[u] = p * CONV_RS + part * 16;
-                        e[u] = (long long)pl[u] * cs + cc + part * 8;
-                    }
-                } else if (it < n_items) {
-                    const int wi = it - n_patch;
-                    const int row = wi >> 2, part = wi & 3;
-                    if (part < parts) {
-                        const int j = row / BN, co = row - j * BN;
-                        pl[u] = -2;          // weight item
-                        ldst[u] = (int)(s_w - s_patch) + row * CONV_RS + part * 16;
-                        e[u] = ((long long)g.tap_slice[tap0 + j] * a.w_rows + co0 + co) * Cin + c0 + part * 8;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_U; ++u) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
-                if (pl[u] >= 0) v[u] = *(const bf16x8*)(src + e[u]);
-                else if (pl[u] == -2) v[u] = *(const bf16x8*)(a.w + e[u]);
-            }
-            if (xform) {
+        // one item = one 16-byte piece (part) of a row; rows 0 .. npix-1 are patch pixels, the rest weight rows.  A
+        // thread keeps its piece index and walks rows in steps of 64, all in 32-bit arithmetic (the host checks the ranges).
+        const int part = tid & 3, n_rows = npix + ntaps * BN;
+        const int w_lds = (int)(s_w - s_patch) - npix * CONV_RS;
+        if (part < parts) {
+            for (int rb = tid >> 2; rb < n_rows; rb += 64 * STAGE_U) {
+                bf16x8 v[STAGE_U];
+                int eo[STAGE_U], pl[STAGE_U], ldst[STAGE_U];
 #pragma unroll
                 for (int u = 0; u < STAGE_U; ++u) {
-                    if (pl[u] < 0) continue;
-                    const int part = (base + u * T) & 3;
-                    if (a.in_add) {
-                        const float* ad = a.in_add + (pl[u] / ihw) * a.C0 + cc + part * 8;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[u][j] = (bf16)((float)v[u][j] + ad[j]);
-                    }
-                    if (a.in_mask) {
-                        const unsigned m = a.in_mask[e[u] >> 3];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[u][j] = (m >> j) & 1 ? (bf16)((float)v[u][j] * a.in_mask_scale) : (bf16)0.f;
+                    const int row = rb + u * 64;
+                    pl[u] = -1; ldst[u] = -1; eo[u] = 0;
+                    if (row < npix) {
+                        pl[u] = s_pl[row];
+                        ldst[u] = row * CONV_RS + part * 16;
+                        eo[u] = pl[u] * cs + cc + part * 8;
+                    } else if (row < n_rows) {
+                        const int wr = row - npix;
+                        const int j = wr / BN, co = wr - j * BN;
+                        pl[u] = -2;          // weight row
+                        ldst[u] = w_lds + row * CONV_RS + part * 16;
+                        eo[u] = (s_tap[j] * a.w_rows + co0 + co) * Cin + c0 + part * 8;
                     }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < STAGE_U; ++u)
-                if (ldst[u] >= 0) *(bf16x8*)(s_patch + ldst[u]) = v[u];
+                for (int u = 0; u < STAGE_U; ++u) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+                    if (pl[u] >= 0) v[u] = *(const bf16x8*)(src + eo[u]);
+                    else if (pl[u] == -2) v[u] = *(const bf16x8*)(a.w + eo[u]);
+                }
+                if (xform) {
+#pragma unroll
+                    for (int u = 0; u < STAGE_U; ++u) {
+                        if (pl[u] < 0) continue;
+                        if (a.in_add) {
+                            const int n = n0 + div_fast(rb + u * 64, g.phw_magic);
+                            const float* ad = a.in_add + n * a.C0 + cc + part * 8;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[u][j] = (bf16)((float)v[u][j] + ad[j]);
+                        }
+                        if (a.in_mask) {
+                            const unsigned m = a.in_mask[eo[u] >> 3];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[u][j] = (m >> j) & 1 ? (bf16)((float)v[u][j] * a.in_mask_scale) : (bf16)0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < STAGE_U; ++u)
+                    if (ldst[u] >= 0) *(bf16x8*)(s_patch + ldst[u]) = v[u];
+            }
         }
         __syncthreads();
-        // -- MFMA over taps x k-steps
-        for (int j = 0; j < ntaps; ++j) {
-            const char* ap = s_patch + a_base + g.tap_poff[tap0 + j] * CONV_RS;
-            const char* bp = s_w + j * BN * CONV_RS + b_base;
-            for (int kk = 0; kk < ksteps; ++kk) {
-                const bf16x8 av = *(const bf16x8*)(ap + kk * 32);
+        if (c0 == 0) CONV_STAMP(2);
+        // -- MFMA over taps x k-steps, software pipelined: the operand fragments of step s + D are requested right after
+        //    the MFMAs of step s have been issued, so the LDS latency of D steps overlaps the matrix pipeline
+        {
+            constexpr int D = NT == 1 ? 4 : 2;
+            const int total = ntaps * ksteps, kshift = ksteps - 1;         // ksteps is 1 or 2
+            bf16x8 fa[D], fb[D][NT];
+            auto fetch = [&](int st, bf16x8& av, bf16x8 (&bv)[NT]) {
+                const int j = st >> kshift, kk = st & kshift;
+                const int poff = __builtin_amdgcn_readlane(my_poff, j);
+                av = *(const bf16x8*)(s_patch + a_base + poff * CONV_RS + kk * 32);
+                const char* bp = s_w + j * BN * CONV_RS + b_base + kk * 32;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 bv = *(const bf16x8*)(bp + nt * 32 * CONV_RS + kk * 32);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const bf16x8*)(bp + nt * 32 * CONV_RS);
+            };
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (d < total) fetch(d, fa[d], fb[d]);
+            for (int s0 = 0; s0 < total; s0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int st = s0 + d;
+                    if (st < total) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d], fb[d][nt], acc[nt], 0, 0, 0);
+                        if (st + D < total) fetch(st + D, fa[d], fb[d]);
+                    }
                 }
             }
         }
+        if (c0 == 0) CONV_STAMP(3);
     }
 
+    CONV_STAMP(4);
     // ---- epilogue
     const int offh = g.cls_off_h[cls], offw = g.cls_off_w[cls];
     if (a.sum_out) {
@@ -181,8 +219,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int ril = row / thw, rr = row - ril * thw;
-                const int rty = rr / g.TW, rtx = rr - rty * g.TW;
+                const int ril = row >> g.thw_shift, rr = row - (ril << g.thw_shift);
+                const int rty = rr >> g.tw_shift, rtx = rr - (rty << g.tw_shift);
                 const int n = n0 + ril, py = oy + rty, px = ox + rtx;
                 const bool ok = n < g.N && py < g.GH && px < g.GW && py * g.SO + offh < g.OH && px * g.SO + offw < g.OW;
                 if (!ok) continue;
@@ -206,8 +244,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int ril = row / thw, rr = row - ril * thw;
-                const int rty = rr / g.TW, rtx = rr - rty * g.TW;
+                const int ril = row >> g.thw_shift, rr = row - (ril << g.thw_shift);
+                const int rty = rr >> g.tw_shift, rtx = rr - (rty << g.tw_shift);
                 const int n = n0 + ril, py = oy + rty, px = ox + rtx;
                 const int oh = py * g.SO + offh, ow = px * g.SO + offw;
                 if (n < g.N && py < g.GH && px < g.GW && oh < g.OH && ow < g.OW)
@@ -216,6 +254,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
         }
         return;
     }
+    CONV_STAMP(5);
     __syncthreads();   // every wave is done reading the operand tiles; reuse LDS for the output tile
     char* s_out = smem;
 #pragma unroll
@@ -229,13 +268,14 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
         }
     }
     __syncthreads();
+    CONV_STAMP(6);
     bf16* out = (bf16*)a.out;
     for (int it = tid; it < BM * (BN / 8); it += T) {
         const int row = it / (BN / 8), part = it - row * (BN / 8);
         const int co = co0 + part * 8;
         if (co >= a.Cout) continue;
-        const int ril = row / thw, rr = row - ril * thw;
-        const int rty = rr / g.TW, rtx = rr - rty * g.TW;
+        const int ril = row >> g.thw_shift, rr = row - (ril << g.thw_shift);
+        const int rty = rr >> g.tw_shift, rtx = rr - (rty << g.tw_shift);
         const int n = n0 + ril, py = oy + rty, px = ox + rtx;
         const int oh = py * g.SO + offh, ow = px * g.SO + offw;
         if (!(n < g.N && py < g.GH && px < g.GW && oh < g.OH && ow < g.OW)) continue;
@@ -257,6 +297,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 4) void conv_mfma_kernel(const C
             for (int j = 0; j < a.Cout - co; ++j) out[e + j] = v[j];
         }
     }
+    CONV_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -320,7 +361,7 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
 
     const int npix = a.g.NB * a.g.PH * a.g.PW;
     const int bm = 32 * cfg.wm, bn = 32 * cfg.nt * cfg.wn;
-    size_t lds = ((size_t)npix * 4 + 15) / 16 * 16 + (size_t)npix * CONV_RS + (size_t)a.g.max_taps * bn * CONV_RS;
+    size_t lds = ((size_t)npix * 4 + 15) / 16 * 16 + CONV_MAX_TAPS * 4 + (size_t)npix * CONV_RS + (size_t)a.g.max_taps * bn * CONV_RS;
     const size_t lds_out = (size_t)bm * (bn * 2 + 16);
     if (lds < lds_out) lds = lds_out;
     DDPM_REQUIRE(lds <= 160 * 1024, "conv: tile needs %zu B of LDS", lds);

@@ -38,3 +38,14 @@ for r in main:
 print("main queue by kernel family:")
 for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print(f"   {k:50s} x{c:3d} {t:8.1f} us")
+shape = collections.defaultdict(lambda: [0, 0.0])
+for r in main:
+    k = r["Kernel_Name"].replace("void ", "")[:48] + " grid " + r.get("Grid_Size_X", r.get("Grid_Size", "?"))
+    shape[k][0] += 1
+    shape[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print("main queue by kernel and grid:")
+for k, (c, t) in sorted(shape.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"   {k:72s} x{c:3d} avg {t / c:7.1f} total {t:8.1f} us")
+print("main queue, first kernels of the step:")
+for r in main[:34]:
+    print(f"   {(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:8.1f}  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>8s}  {r['Kernel_Name'][:110]}")
