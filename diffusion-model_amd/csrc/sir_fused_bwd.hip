@@ -382,6 +382,11 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
             col_store<E, M, E>(wg, wave, v1, lane, tab);
             __syncthreads();
             for (int c = tid; c < E; c += SIR_THREADS) dwp[tap * E + c] = col_total<1, E>(tab, 0, c);
+            // pins the accumulators between taps: left alone, the scheduler interleaves the taps' neighbour reads and spills
+#pragma unroll
+            for (int k = 0; k < E1::NV; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[k][j]));
         }
 #pragma unroll
         for (int k = 0; k < E1::NV; ++k)
