@@ -13,7 +13,8 @@
 __global__ __launch_bounds__(256) void remap_kernel(const ddpm_remap_entry* __restrict__ entries, const int2* __restrict__ chunks,
                                                      int to_a) {
     const int2 ch = chunks[blockIdx.x];
-    const ddpm_remap_entry e = entries[ch.x];
+    const ddpm_remap_entry* __restrict__ ep = entries + ch.x;      // off_s is indexed per element: a by-value copy of the entry would live in scratch memory
+    struct { int S, R, K, Rv, Kv, a_r, a_k, a_bf16; void* a; void* b; } e = {ep->S, ep->R, ep->K, ep->Rv, ep->Kv, ep->a_r, ep->a_k, ep->a_bf16, (void*)ep->a, (void*)ep->b};
     // one tensor has far fewer than 2^31 elements (checked by the host side when the table is built): 32-bit index
     // arithmetic, whose divisions cost a fraction of the 64-bit ones
     const unsigned total = (unsigned)e.S * (unsigned)e.R * (unsigned)e.K;
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void remap_kernel(const ddpm_remap_entry* __re
         const int k = (int)(i - sr * K);
         const int s = (int)(sr / R), r = (int)(sr - (unsigned)s * R);
         const bool valid = r < e.Rv && k < e.Kv;
-        const int bi = r * e.a_r + k * e.a_k + e.off_s[s];
+        const int bi = r * e.a_r + k * e.a_k + ep->off_s[s];
         if (to_a) {
             const float v = valid ? ((const float*)e.b)[bi] : 0.f;
             if (e.a_bf16) ((bf16*)e.a)[i] = (bf16)v;

@@ -509,7 +509,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
         float bd[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) bd[j] = s_p[P_BD + v1 * 8 + j];
-#pragma unroll 1
+#pragma unroll
         for (int k0 = 0; k0 < E1::NV; k0 += KB) {
             float acc[KB][8];
 #pragma unroll
@@ -540,10 +540,8 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[k][j];
-                // xr[] is indexed at run time here (k0 is a loop counter): select by compile-time comparison to stay in registers
-#pragma unroll
-                for (int q = 0; q < E1::NV; ++q)
-                    if (q == k0 + k) xr[q] = o;
+                xr[k0 + k] = o;
+                asm volatile("" : "+v"(xr[k0 + k]));       // convert now: keeps the chunks from being interleaved (which spills)
             }
         }
     }
