@@ -302,6 +302,29 @@ extern "C" int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int 
 }
 
 // Advance a device-resident 64-bit seed by one (so a replayed graph draws fresh randomness each step).
+// t ~ U{1..T} per image (base_trainer.py:202 there draws it with torch.randint): Philox word i of the (seed, stream) sequence,
+// mapped to the range by multiply-high.  Drawing it here keeps the framework's generator (and the bookkeeping kernels
+// a captured graph needs for it) out of the training step.
+__global__ __launch_bounds__(256) void sample_timesteps_kernel(long long* __restrict__ t, int N, int T,
+                                                                const unsigned long long* __restrict__ seed, unsigned stream_id) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= N) return;
+    const unsigned long long sd = *seed;
+    const Philox4 r = philox4x32_10((uint32_t)q, 0u, stream_id, 0x3c6ef372u, (uint32_t)sd, (uint32_t)(sd >> 32));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < N) t[q * 4 + j] = 1 + (long long)(((unsigned long long)w[j] * (unsigned)T) >> 32);
+}
+
+extern "C" int ddpm_sample_timesteps(int64_t* t, int N, int T, const uint64_t* seed, uint32_t stream_id, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(t && seed && N > 0 && T > 0, "sample_timesteps: bad arguments");
+    hipLaunchKernelGGL(sample_timesteps_kernel, dim3((N + 1023) / 1024), dim3(256), 0, stream, (long long*)t, N, T,
+                       (const unsigned long long*)seed, stream_id);
+    return ddpm_check_launch("sample_timesteps");
+}
+
 __global__ void bump_seed_kernel(unsigned long long* seed) { *seed += 0x9E3779B97F4A7C15ull; }
 
 extern "C" int ddpm_bump_seed(uint64_t* seed_, ddpm_stream_t stream_) {

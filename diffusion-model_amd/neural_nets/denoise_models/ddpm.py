@@ -97,6 +97,18 @@ class DDPM(nn.Module):
             hip.call("ddpm_bump_seed", hip.ptr(seed), hip.stream())
         return out
 
+    @torch.no_grad()
+    def sample_timesteps(self, n: int, device=None, out: Optional[Tensor] = None) -> Tensor:
+        """t ~ U{1..T} for n images (base_trainer.py:202 there: torch.randint(1, T + 1, (n,))), drawn in-kernel from the
+        module's Philox seed (stream 3; the seed advances with the next q()).  Unlike torch.randint it involves no
+        framework generator, so a captured training step carries no generator bookkeeping."""
+        dev = _as_device(device if device is not None else self.device)
+        if dev.type != "cuda":
+            raise RuntimeError("DDPM.sample_timesteps runs on the HIP kernels only: it needs an MI355X (cuda) device")
+        t = out if out is not None else torch.empty(n, device=dev, dtype=torch.long)
+        hip.call("ddpm_sample_timesteps", hip.ptr(t), n, self.T, hip.ptr(self._rng_seed(dev)), 3, hip.stream())
+        return t
+
     def forward(self, *args, **kwargs):
         return self.model(*args, **kwargs)
 

@@ -65,7 +65,7 @@ class GraphedTrainStep:
     def _front(self):
         n = self.x0.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
-        t = torch.randint(1, self.core.T + 1, (n,), device=self.x0.device)
+        t = self.core.sample_timesteps(n, self.x0.device)
         x_t = self.core.q(self.x0, t)
         pred = self.ddpm(x_t, t)
         loss = self.criterion(self.ddpm, t, pred, self.x0, is_ddp=hasattr(self.ddpm, "module"))["Loss"]
@@ -178,7 +178,7 @@ class PipelinedTrainStep:
             return
         from . import hip
         core, n = self.core, self.x0.shape[0]
-        t = torch.randint(1, core.T + 1, (n,), device=self.x0.device)
+        t = core.sample_timesteps(n, self.x0.device)
         x_t = core.q(self.x0, t)
         params = dict(zip(self.unet._param_names, self.unet.parameters()))
         pred, self._ctx = self.eng.forward(params, x_t, t, train=self.unet.training, record=True)

@@ -78,6 +78,9 @@ int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int C, int HW, 
 int ddpm_tanh_bwd_nchw_to_nhwc(const float* dy, const float* y, void* dz, int N, int C, int HW, int cpad, ddpm_stream_t stream);
 /* *seed += odd constant: lets a replayed HIP graph draw fresh randomness every step. */
 int ddpm_bump_seed(uint64_t* seed, ddpm_stream_t stream);
+/* t[i] ~ U{1..T}, the per-image training timestep (base_trainer.py:202: torch.randint(1, T + 1, (N,))): Philox4x32-10
+ * word i of the (*seed, stream_id) sequence mapped to the range by multiply-high.  t: device int64 [N]. */
+int ddpm_sample_timesteps(int64_t* t, int N, int T, const uint64_t* seed, uint32_t stream_id, ddpm_stream_t stream);
 
 /* Dataset transforms of the reference on the GPU (datasets/mnist.py:26-39, datasets/flowers102.py:28-38, augmentation/
  * augmentation.py:13): transforms.Resize (PIL bilinear, two fixed-point passes) -> ToTensor -> x*2-1 -> channel

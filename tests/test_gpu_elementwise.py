@@ -114,3 +114,25 @@ def test_layout_bridges(dev):
     hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(y), hip.ptr(dz), 3, 3, 64, 16, hip.stream())
     ref = (dy * (1 - y * y)).permute(0, 2, 3, 1)
     torch.testing.assert_close(dz[..., :3].float(), ref, rtol=1e-2, atol=1e-3)
+
+
+def test_timesteps_match_the_philox_oracle_bit_for_bit(dev):
+    """Integer work: every drawn timestep equals the numpy restatement (oracle/philox.py, pinned by Random123's known-answer
+    vectors); ragged sizes; a bumped seed gives a different draw."""
+    from oracle.philox import sample_timesteps
+    for n, T, sd, sid in [(256, 120, 1234, 3), (1, 1000, 2 ** 61 + 12345, 0), (1027, 7, 99, 5)]:
+        seed = torch.tensor([sd], device=dev, dtype=torch.int64)
+        t = torch.full((n + 3,), -7, device=dev, dtype=torch.long)
+        hip.call("ddpm_sample_timesteps", hip.ptr(t), n, T, hip.ptr(seed), sid, hip.stream())
+        got = t.cpu().numpy()
+        assert (got[n:] == -7).all(), "wrote past the end"
+        assert (got[:n] == sample_timesteps(n, T, sd, sid)).all()
+        assert got[:n].min() >= 1 and got[:n].max() <= T
+    seed = torch.tensor([1234], device=dev, dtype=torch.int64)
+    a, b = (torch.empty(4096, device=dev, dtype=torch.long) for _ in range(2))
+    hip.call("ddpm_sample_timesteps", hip.ptr(a), 4096, 120, hip.ptr(seed), 3, hip.stream())
+    hip.call("ddpm_bump_seed", hip.ptr(seed), hip.stream())
+    hip.call("ddpm_sample_timesteps", hip.ptr(b), 4096, 120, hip.ptr(seed), 3, hip.stream())
+    assert not torch.equal(a, b)
+    counts = torch.bincount(a.cpu(), minlength=121)[1:].float()
+    assert counts.min() > 10 and counts.max() < 70          # 4096 / 120 = 34 expected per value

@@ -172,3 +172,17 @@ def test_conditional_module_gradients(golden, name):
         close(grads[1], c["dcond"], 1e-3, 1e-4)
     for k, gk in zip(leaves, grads[len(ins):]):
         close(gk, c["dparams"][k], 1e-3, 2e-4)
+
+
+def test_philox_oracle_known_answers():
+    """Random123 kat_vectors, philox4x32 with 10 rounds: (counter, key) -> output."""
+    import numpy as np
+    from oracle.philox import philox4x32_10, sample_timesteps
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(x[0]) for x in philox4x32_10(*[np.array([v]) for v in ctr], *key))
+        assert got == want
+    t = sample_timesteps(10000, 120, 42, 3)
+    assert t.min() == 1 and t.max() == 120 and t.dtype == np.int64
