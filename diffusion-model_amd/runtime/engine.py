@@ -153,6 +153,10 @@ class UNetEngine:
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
+        self.mask_ahead = False        # keep bits drawn one step ahead by the driver (see _make_masks)
+        self._mask_bufs: Dict = {}
+        self._mask_key = None
+        self._mask_seed = None
         self.fuse_embed = True          # all time-embedding MLPs in one forward and one backward launch
         self.wgrad_tiles_per_split = 8  # grouped weight gradients: 128-position tiles per position split
         self.wgrad_tiles_last = 2       # the same for the last phase of a multi-phase backward, whose group launch runs alone
@@ -202,7 +206,11 @@ class UNetEngine:
         return sizes
 
     def _make_masks(self, key, sizes_fn: Callable[[], List[int]], device) -> List[Tensor]:
-        """One keep-bit buffer for all dropout sites of a pass (element counts from sizes_fn, cached under key)."""
+        """One keep-bit buffer for all dropout sites of a pass (element counts from sizes_fn, cached under key).
+
+        mask_ahead mode (the pipelined training step): the buffer is persistent and is NOT filled here; the driver draws
+        the next step's bits into a second buffer while this step computes (generate_masks) and copies them over once
+        the step's last reader is done (commit_masks).  The first call of a shape fills the buffer directly."""
         if key not in self._mask_offsets:
             sizes = sizes_fn()
             nbytes = [(s // 8 + 3) // 4 * 4 for s in sizes]
@@ -211,13 +219,41 @@ class UNetEngine:
                 offs.append(offs[-1] + b)
             self._mask_offsets[key] = (torch.tensor(offs, device=device, dtype=torch.long), offs, len(sizes))
         offs_dev, offs, nsites = self._mask_offsets[key]
-        buf = torch.empty(offs[-1], device=device, dtype=torch.uint8)
         if self.seed is None:
             self.seed = torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.long)
-        hip.call("ddpm_bump_seed", hip.ptr(self.seed), hip.stream())
-        hip.call("ddpm_dropout_masks", hip.ptr(buf), hip.ptr(offs_dev), nsites, offs[-1], 1.0 - self.spec.drop_p, hip.ptr(self.seed),
-                 hip.stream())
+        if self.mask_ahead:
+            if key not in self._mask_bufs:
+                self._mask_bufs[key] = (torch.empty(offs[-1], device=device, dtype=torch.uint8), torch.empty(offs[-1], device=device, dtype=torch.uint8))
+                self._mask_seed = self.seed ^ 0x5DEECE66D
+                self._mask_key = key
+                self.generate_masks(ahead=False)
+                self.generate_masks(ahead=True)
+            buf = self._mask_bufs[key][0]
+        else:
+            buf = torch.empty(offs[-1], device=device, dtype=torch.uint8)
+            hip.call("ddpm_bump_seed", hip.ptr(self.seed), hip.stream())
+            hip.call("ddpm_dropout_masks", hip.ptr(buf), hip.ptr(offs_dev), nsites, offs[-1], 1.0 - self.spec.drop_p, hip.ptr(self.seed),
+                     hip.stream())
         return [buf[offs[i]:offs[i + 1]] for i in range(nsites)]
+
+    def generate_masks(self, ahead: bool = True) -> None:
+        """mask_ahead mode: draw fresh keep bits (own seed, advanced here) into the stand-by buffer (ahead) or the live one."""
+        if self._mask_key is None:
+            return
+        offs_dev, offs, nsites = self._mask_offsets[self._mask_key]
+        buf = self._mask_bufs[self._mask_key][1 if ahead else 0]
+        hip.call("ddpm_bump_seed", hip.ptr(self._mask_seed), hip.stream())
+        hip.call("ddpm_dropout_masks", hip.ptr(buf), hip.ptr(offs_dev), nsites, offs[-1], 1.0 - self.spec.drop_p, hip.ptr(self._mask_seed),
+                 hip.stream())
+
+    def commit_masks(self) -> None:
+        """mask_ahead mode, after the last reader of a step: the stand-by bits become the live ones; the seed of the
+        in-kernel (attention) dropout advances."""
+        if self._mask_key is None:
+            return
+        live, ahead = self._mask_bufs[self._mask_key]
+        live.copy_(ahead)
+        hip.call("ddpm_bump_seed", hip.ptr(self.seed), hip.stream())
 
     def _open(self, params: Dict[str, Tensor], n: int, dev, rkey, train: bool, record: bool, masks, site_sizes, taps=None):
         """Start a pass: returns a namespace of the fused-unit builders (conv_unit, dw_unit, sir, embed, ...) bound to this

@@ -106,8 +106,12 @@ class PipelinedTrainStep:
     driver replays, per phase p, a graph M_p (data-gradient chain) on the main stream and a graph W_p (the phase's leaf
     work) on a side stream, W_p beside M_{p+1}:
 
-        main:  [A: t, q, forward, ELBO, M_0] [M_1] [M_2] [M_3] ........ wait side -> [C: Adam]
-        side:                         [W_0]  [W_1]  [W_2]  [W_3 + gradients to torch layout]
+        main:  [A: t, q, forward, ELBO, M_0] [M_1] [M_2] [M_3] ........ wait side ( -> [C: Adam] when data parallel)
+        side:  [next step's dropout bits]     [W_0]  [W_1]  [W_2]  [W_3 + gradients to torch layout + Adam]
+
+    Single GPU: the optimizer step closes the last leaf graph (every graph start costs tens of microseconds on the device,
+    so the critical path holds as few as possible), and the next step's dropout keep bits are drawn by two plain launches
+    at the head of the side stream, beside the forward pass (double-buffered in the engine: mask_ahead).
 
     (4 phases measured best: with one phase per stage the leaf launches become too small to keep the side stream ahead.
     The last phase's leaf work runs alone, so its weight-gradient problems are cut into more, shorter position splits.)
@@ -127,6 +131,7 @@ class PipelinedTrainStep:
         self.unet = self.core.model
         self.eng = self.unet._get_engine()
         self.eng.always_repack = True
+        self.eng.mask_ahead = True
         if int(phases) < 2:
             raise ValueError("phases must be 2, 4 or larger (= one phase per stage)")
         self.eng.phases = int(phases)
@@ -143,6 +148,7 @@ class PipelinedTrainStep:
         self.graphs = None
         self.side = torch.cuda.Stream()
         self.events = [torch.cuda.Event() for _ in range(self.K)]
+        self.ev_done = torch.cuda.Event()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -154,6 +160,7 @@ class PipelinedTrainStep:
             # capture in execution order; every graph has its own memory pool, so what a side graph still reads is never
             # handed to a later main graph's allocations
             gm, gw = [], []
+            gp = self.eng._mask_key is not None         # dropout: the next step's keep bits are drawn beside the forward pass
             for p in range(self.K):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -163,11 +170,13 @@ class PipelinedTrainStep:
                 with torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
                     self._leaf(p)
                 gw.append(g)
-            gc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gc, capture_error_mode="thread_local"):
-                self._adam()
+            gc = None
+            if self.reducer is not None:
+                gc = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gc, capture_error_mode="thread_local"):
+                    self._adam()
             torch.cuda.synchronize()
-            self.graphs = (gm, gw, gc)
+            self.graphs = (gm, gw, gc, gp)
 
     # ---- pieces ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -210,10 +219,21 @@ class PipelinedTrainStep:
                 for name, prm in zip(self.unet._param_names, self.unet.parameters()):
                     prm.grad = views[name]
                 self._bound = True
+            if self.reducer is None:
+                # single GPU: nothing comes between the last gradient and the optimizer, so the update rides at the end
+                # of this graph instead of paying a graph start of its own on the main stream
+                self._adam()
 
     @torch.no_grad()
     def _adam(self):
         self.optimizer.step()
+        self.eng.commit_masks()
+
+    @torch.no_grad()
+    def _pre(self):
+        """side-stream work beside the forward pass: the NEXT step's dropout keep bits (ALU-bound, fits the gaps of the
+        latency-bound forward), into the stand-by buffer that _adam() makes live after this step's last reader"""
+        self.eng.generate_masks(ahead=True)
 
     def _exchange(self, p: int):
         """called with the side stream current, right after W_p was queued on it"""
@@ -230,7 +250,16 @@ class PipelinedTrainStep:
 
     def _run(self, graphs, exchange: bool = True):
         main = torch.cuda.current_stream()
-        gm, gw, gc = graphs if graphs is not None else (None, None, None)
+        gm, gw, gc, gp = graphs if graphs is not None else (None, None, None, None)
+        if graphs is None:
+            self._pre()
+        elif gp:
+            # two plain launches with persistent arguments, not a graph: a graph launch costs tens of microseconds of
+            # start-up on the device and would delay the start of the forward graph behind it
+            if self.reducer is not None:
+                self.side.wait_event(self.ev_done)      # the previous step's commit (main stream) has read the stand-by buffer
+            with torch.cuda.stream(self.side):          # single GPU: the commit is earlier work of the side stream itself
+                self._pre()
         for p in range(self.K):
             if gm is None:
                 self._main(p)
@@ -253,10 +282,13 @@ class PipelinedTrainStep:
         for h in self._handles:
             self.reducer.finish(h)
         self._handles.clear()
+        if self.reducer is None:
+            return                                      # the optimizer step was part of the last leaf graph
         if gc is None:
             self._adam()
         else:
             gc.replay()
+            self.ev_done.record(main)
 
     def local_body(self):
         """one eager step without the exchange (per-kernel timing on one rank must not enter a collective)"""
