@@ -215,6 +215,13 @@ def main():
         from dm_amd.runtime import roofline
         rows = [] if a.detail else None
         out["roofline"] = roofline.measure(step.local_body, traffic_file=os.path.join(ROOT, "profiles", "hbm_traffic.json"), detail=rows)
+        pk = os.path.join(ROOT, "profiles", "r01_peaks.json")      # what this kind of device delivered to a plain read / MFMA loop (tools/peaks)
+        if os.path.exists(pk):
+            with open(pk) as f:
+                m_ = json.load(f)
+            r_ = out["roofline"]
+            r_["peak_measured"] = m_["hbm_read_GBs"] if r_["bound"] == "hbm" else m_["mfma_bf16_dense_TFLOPs"]
+            r_["frac_of_measured"] = r_["achieved"] / r_["peak_measured"]
         if rows:
             with open(a.detail, "w") as f:
                 for k, cnt, us, gbs, tf in sorted(rows, key=lambda r: -r[1] * r[2]):
