@@ -7,6 +7,10 @@
 // its four waves split the input channels four ways, each streaming its weight fragments straight from L2 with a tap
 // of look-ahead; the four partial tiles are added through LDS.  Same operands, fused input transforms (channel concat,
 // time-embedding add) and epilogue (bias, activation, residual, per-image sums) as the general kernel.
+//
+// A 32-row tile is 8 (2x2) or 2 (4x4) whole images and 32 output channels are whole normalisation groups, so the
+// GroupNorm + activation that follows every such convolution in the UNet (conv_block.py:19-54 there) can finish in
+// the same launch: `out` still receives the raw result (the backward pass needs it), gn_out the normalised one.
 #include "conv_geom.h"
 #include "ddpm_hip.h"
 
@@ -17,6 +21,9 @@ struct SmallConvArgs {
     bf16* out; const bf16* res;
     float* sum_out;
     int N, Cout, out_cs, w_rows, act;
+    // optional fused GroupNorm + activation (+ residual) of the result: a tile holds whole images and whole groups
+    const float* gn_gamma; const float* gn_beta; bf16* gn_out; float* gn_stats; const bf16* gn_res;
+    int gn_groups, gn_act; float gn_eps;
 };
 
 template <int W>
@@ -96,39 +103,112 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
         s_red[(wave * 32 + row) * 33 + (lane & 31)] = acc[i];
     }
     __syncthreads();
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    const long long grow = row0 + row;
+    const bool live = grow < rows_total;
+    const long long e = grow * a.out_cs + co0 + c4;
+    float val[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + c4 + j;
+        const float v = s_red[(0 * 32 + row) * 33 + c4 + j] + s_red[(1 * 32 + row) * 33 + c4 + j] +
+                        s_red[(2 * 32 + row) * 33 + c4 + j] + s_red[(3 * 32 + row) * 33 + c4 + j];
+        val[j] = act_fwd(v + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
+    }
+    if (live) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)val[j];
+        if (a.sum_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co0 + c4 + j < a.Cout) atomicAdd(a.sum_out + (grow / HW) * a.Cout + co0 + c4 + j, val[j]);
+        }
+        if (a.res) {
+            const bf16x4 rv = *(const bf16x4*)(a.res + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] + (float)rv[j]);
+        }
+        if (co0 + c4 + 4 <= a.Cout) {
+            *(bf16x4*)(a.out + e) = o;
+        } else {
+            for (int j = 0; j < a.Cout - co0 - c4; ++j) a.out[e + j] = o[j];
+        }
+    }
+    if (!a.gn_gamma) return;
+
+    // ---- fused GroupNorm + activation: statistics over the bf16-rounded raw values, as the separate kernel would read them
+    const int cpg = a.Cout / a.gn_groups;              // 32 % cpg == 0, Cout % 32 == 0, no conv activation / residual (host-checked)
+    const int gpt = 32 / cpg;                          // groups in this tile
+    f32x4 gam = *(const f32x4*)(a.gn_gamma + co0 + c4), bet = *(const f32x4*)(a.gn_beta + co0 + c4);
+    bf16x4 rv4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rv4[j] = (bf16)0.f;
+    if (a.gn_res && live) rv4 = *(const bf16x4*)(a.gn_res + e);
+    __syncthreads();                                   // partial tiles consumed: reuse the table as [32][33] values + [32 pairs][2] statistics
+    float* s_val = s_red;
+    float* s_st = s_red + 32 * 33;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        val[j] = (float)(bf16)val[j];
+        s_val[row * 33 + c4 + j] = live ? val[j] : 0.f;
+    }
+    __syncthreads();
     {
-        const int row = tid >> 3, c4 = (tid & 7) * 4;
-        const long long grow = row0 + row;
-        if (grow < rows_total) {
-            bf16x4 o;
-            float sums[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = co0 + c4 + j;
-                float v = s_red[(0 * 32 + row) * 33 + c4 + j] + s_red[(1 * 32 + row) * 33 + c4 + j] +
-                          s_red[(2 * 32 + row) * 33 + c4 + j] + s_red[(3 * 32 + row) * 33 + c4 + j];
-                v = act_fwd(v + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
-                sums[j] = v;
-                o[j] = (bf16)v;
+        // pair = (image of the tile, group of the tile); eight threads per pair, HW * cpg / 8 values each
+        const int pair = tid >> 3, sub = tid & 7;
+        const int npairs = (32 / HW) * gpt;
+        float s1 = 0.f, s2 = 0.f;
+        if (pair < npairs) {
+            const int img = pair / gpt, grp = pair - img * gpt;
+            const int per = HW * cpg / 8;
+            for (int q = sub * per; q < (sub + 1) * per; ++q) {
+                const int r2 = img * HW + q / cpg, c2 = grp * cpg + q % cpg;
+                const float f = s_val[r2 * 33 + c2];
+                s1 += f; s2 += f * f;
             }
-            if (a.sum_out) {
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (co0 + c4 + j < a.Cout) atomicAdd(a.sum_out + (grow / HW) * a.Cout + co0 + c4 + j, sums[j]);
-            }
-            const long long e = grow * a.out_cs + co0 + c4;
-            if (a.res) {
-                const bf16x4 rv = *(const bf16x4*)(a.res + e);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] + (float)rv[j]);
-            }
-            if (co0 + c4 + 4 <= a.Cout) {
-                *(bf16x4*)(a.out + e) = o;
-            } else {
-                for (int j = 0; j < a.Cout - co0 - c4; ++j) a.out[e + j] = o[j];
+        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (pair < npairs && sub == 0) {
+            const int img = pair / gpt, grp = pair - img * gpt;
+            const float m = 1.0f / (float)(HW * cpg);
+            const float mean = s1 * m;
+            const float rstd = rsqrtf(fmaxf(s2 * m - mean * mean, 0.f) + a.gn_eps);
+            s_st[pair * 2] = mean; s_st[pair * 2 + 1] = rstd;
+            const long long n = row0 / HW + img;
+            if (n < a.N && a.gn_stats) {
+                const int g = co0 / cpg + grp;
+                a.gn_stats[(n * a.gn_groups + g) * 2 + 0] = mean;
+                a.gn_stats[(n * a.gn_groups + g) * 2 + 1] = rstd;
             }
         }
     }
+    __syncthreads();
+    if (live) {
+        const int pair = (row / HW) * gpt + c4 / cpg;  // cpg >= 4: the four channels of a thread share a group
+        const float mean = s_st[pair * 2], rstd = s_st[pair * 2 + 1];
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sc = gam[j] * rstd, sh = bet[j] - mean * sc;
+            float y = act_fwd(val[j] * sc + sh, a.gn_act);
+            if (a.gn_res) y += (float)rv4[j];
+            o[j] = (bf16)y;
+        }
+        *(bf16x4*)(a.gn_out + grow * a.Cout + co0 + c4) = o;
+    }
+}
+
+// Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
+extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
+    if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4)) return 0;
+    if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->res || d->act != 0 || d->sum_out) return 0;
+    const int Cin = d->C0 + d->C1;
+    if (Cin % 64 || Cin > 512 || d->C0 % 8 || d->C1 % 8 || d->out_cs != d->Cout) return 0;
+    if (d->gn_groups <= 0 || d->Cout % 32 || d->Cout % d->gn_groups) return 0;
+    const int cpg = d->Cout / d->gn_groups;
+    return cpg >= 4 && cpg <= 32 && 32 % cpg == 0;
 }
 
 // Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
@@ -141,7 +221,13 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1; a.in_add = d->in_add;
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out; a.res = (const bf16*)d->res; a.sum_out = d->sum_out;
     a.N = d->N; a.Cout = d->Cout; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act;
-    const size_t lds = (size_t)33 * (Cin * 2 + 16) + 4 * 32 * 33 * 4;
+    a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_out = (bf16*)d->gn_out; a.gn_stats = d->gn_stats; a.gn_res = (const bf16*)d->gn_res;
+    a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps;
+    if (d->gn_gamma && !(d->gn_beta && d->gn_out && ddpm_conv_gn_fusable(d))) {
+        ddpm_set_error("conv: the fused GroupNorm needs gamma, beta, an output and a shape ddpm_conv_gn_fusable() accepts");
+        return -1;
+    }
+    const size_t lds = (size_t)33 * (Cin * 2 + 16) + 4 * 32 * 33 * 4;      // the statistics table of the fused GroupNorm fits the partial-tile area
     const long long rows = (long long)d->N * d->IH * d->IW;
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)(d->CoutW / 32));
     if (d->IW == 2) {

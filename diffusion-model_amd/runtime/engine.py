@@ -350,12 +350,18 @@ class UNetEngine:
                 # inference, no normalisation: the activation runs in the convolution's epilogue (no pre-activation is kept)
                 return Var(ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                             in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act=act))
-            raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
-                                   in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
             gamma = P[norm + ".weight"] if norm else None
             beta = P[norm + ".bias"] if norm else None
-            y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
-                                          mask=out_mask, mask_scale=mscale)
+            if norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
+                # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
+                raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
+                                                 in_add=None if in_add is None else in_add.v,
+                                                 gn=(gamma, beta, groups, act, None if res is None else res.v))
+            else:
+                raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
+                                       in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
+                y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
+                                              mask=out_mask, mask_scale=mscale)
             out = Var(y)
             if tape is not None:
                 tape.append(conv_bwd(name, x0, x1, in_add, in_mask, raw, out, stats, norm, groups, act, res, out_mask))

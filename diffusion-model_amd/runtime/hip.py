@@ -29,6 +29,8 @@ class ConvDesc(C.Structure):
         ("out", _vp), ("res", _vp), ("out_mask", _vp), ("out_mask_scale", _f),
         ("Cout", _i), ("CoutW", _i), ("out_cs", _i), ("w_rows", _i),
         ("act", _i), ("out_mode", _i), ("sum_out", _vp),
+        ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_stats", _vp), ("gn_res", _vp),
+        ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f),
     ]
 
 
@@ -111,6 +113,7 @@ _PROTOS = {
     "ddpm_sample_timesteps": ([_vp, _i, _i, _vp, _u32, _vp], _i),
     "ddpm_prepare_images": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
+    "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_scratch_floats": ([C.POINTER(GnDesc), _i], _i64),

@@ -49,10 +49,12 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                  in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0, act: int = 0,
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
                  out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
-                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None) -> Tensor:
+                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None):
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
     (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
-    sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res."""
+    sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res.
+    gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
+    where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone."""
     n, ih, iw, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     assert x0.dtype == BF16 and x0.is_contiguous() and w.dtype == BF16 and w.is_contiguous()
@@ -69,16 +71,31 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      CoutW=(w.shape[1] if rows is None else (rows + 31) // 32 * 32), out_cs=(0 if f32_nchw else out.shape[3]),
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out))
+    y = stats = None
+    if gn is not None:
+        gamma, beta, groups, gact, gres = gn
+        y = torch.empty(n, oh, ow, cout, device=x0.device, dtype=BF16)
+        stats = torch.empty(n, groups, 2, device=x0.device, dtype=torch.float32)
+        d.gn_gamma, d.gn_beta, d.gn_out, d.gn_stats, d.gn_res = hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(stats), hip.ptr(gres)
+        d.gn_groups, d.gn_act, d.gn_eps = groups, gact, 1e-5
 
     def cost():
         # every operand once: activations in, weight rows used, bias, epilogue operands, result
         wbytes = _SLICES[kind] * d.CoutW * (c0 + c1) * 2
         obytes = n * oh * ow * cout * (4 if f32_nchw else 2)
-        return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out) + wbytes + cout * 4 + obytes,
+        return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out, y, stats, None if gn is None else gn[4]) + wbytes + cout * 4 + obytes,
                 2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}")
 
     _launch("conv_mfma_kernel", cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
-    return out
+    return out if gn is None else (out, y, stats)
+
+
+def conv_gn_fusable(kind: int, x0: Tensor, x1: Optional[Tensor], cout: int, groups: int) -> bool:
+    """Whether conv_forward(..., gn=...) is available for this convolution (no masks, no conv-side activation / residual)."""
+    n, ih, iw, c0 = x0.shape
+    d = hip.ConvDesc(kind=kind, N=n, IH=ih, IW=iw, C0=c0, C1=0 if x1 is None else x1.shape[3], Cout=cout, out_cs=cout,
+                     out_mode=hip.OUT_BF16_NHWC, gn_groups=groups)
+    return bool(hip.lib().ddpm_conv_gn_fusable(C.byref(d)))
 
 
 def wgrad_desc(kind, x0, dy, cout, dw, part, x1, in_add, in_mask, in_scale, tiles_per_split=0):

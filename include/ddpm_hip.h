@@ -115,7 +115,16 @@ typedef struct ddpm_conv_desc {
     float* sum_out;            /* optional fp32 [N][Cout] += per-image sum over output pixels of act(conv + bias), taken from the
                                 * fp32 accumulators before mask / res: with a data-gradient kind this is the gradient of the
                                 * broadcast time-embedding add (unets.py:128,237).  Caller zeroes it. */
+    /* Optional fused GroupNorm + activation (+ residual) of the result (conv -> GroupNorm -> act, conv_block.py:19-54), where
+     * ddpm_conv_gn_fusable() says one workgroup holds whole images and whole groups: `out` receives the raw convolution as
+     * before (the backward pass needs it), gn_out [N][OH][OW][Cout] = act(GroupNorm(raw)) + gn_res, gn_stats [N][G][2] =
+     * mean, rstd.  gn_gamma == NULL: no fused GroupNorm. */
+    const float* gn_gamma; const float* gn_beta;
+    void* gn_out; float* gn_stats; const void* gn_res;
+    int gn_groups, gn_act;
+    float gn_eps;
 } ddpm_conv_desc;
+int ddpm_conv_gn_fusable(const ddpm_conv_desc* d);
 
 /* y = act(conv(x) + bias) [* mask] [+ res] for every kind above. */
 int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream);

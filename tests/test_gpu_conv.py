@@ -120,3 +120,48 @@ def test_conv_rejects_bad_shapes(dev):
     w = torch.zeros(1, 32, 24, device=dev, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="multiples of 16"):
         ops.conv_forward(hip.CONV_1X1, x, w, None, 32)
+
+
+@pytest.mark.parametrize("n,ci,c1,co,hw,groups,act,with_res,with_add", [
+    (9, 256, 0, 256, 2, 16, "gelu", False, True),      # ragged last tile (9 images of 4 pixels: 36 rows)
+    (5, 128, 0, 128, 4, 16, "silu", True, False),
+    (4, 256, 256, 256, 2, 16, "gelu", False, True),    # decoder: concatenated skip connection
+    (3, 256, 0, 512, 2, 32, "relu", False, False),
+])
+def test_conv_with_fused_groupnorm(dev, n, ci, c1, co, hw, groups, act, with_res, with_add):
+    """conv -> GroupNorm -> act (+ residual) finished inside the convolution's launch (2x2 / 4x4 images): raw result,
+    statistics and normalised output against torch fp32 on the same bf16-rounded operands.  Tolerance 1e-2 of the scale
+    for the bf16 tensors, 1e-3 relative for the statistics."""
+    from oracle import ref_cpu as O
+    x = r16(hash_normal((n, ci, hw, hw), 61))
+    xb = r16(hash_normal((n, c1, hw, hw), 62)) if c1 else None
+    w = r16(hash_normal((co, ci + c1, 3, 3), 63) * (1.5 / (3 * (ci + c1) ** 0.5)))
+    b = hash_normal((co,), 64) * 0.1
+    gamma, beta = 1 + 0.3 * hash_normal((co,), 65), 0.3 * hash_normal((co,), 66)
+    res = r16(hash_normal((n, co, hw, hw), 67)) if with_res else None
+    add = hash_normal((n, ci), 68) * 0.5 if with_add else None
+    xin = x if add is None else r16(x + add[:, :, None, None])
+    raw_ref = r16(F.conv2d(xin if xb is None else torch.cat([xin, xb], 1), w, b, padding=1))
+    y_ref = O.act_fn(act)(F.group_norm(raw_ref, groups, gamma, beta, eps=1e-5))
+    if with_res:
+        y_ref = y_ref + res
+    g = raw_ref.view(n, groups, -1)
+    mean_ref, rstd_ref = g.mean(2), (g.var(2, unbiased=False) + 1e-5).rsqrt()
+
+    x0d, x1d = nhwc(x, dev), (nhwc(xb, dev) if xb is not None else None)
+    assert ops.conv_gn_fusable(hip.CONV_3X3_S1, x0d, x1d, co, groups)
+    raw, y, stats = ops.conv_forward(hip.CONV_3X3_S1, x0d, pack.pack_fwd(hip.CONV_3X3_S1, w).to(dev), b.to(dev), co, x1=x1d,
+                                     in_add=None if add is None else add.to(dev),
+                                     gn=(gamma.to(dev), beta.to(dev), groups, hip.ACT[act], None if res is None else nhwc(res, dev)))
+    assert_rel(nchw(raw), raw_ref)
+    assert_rel(nchw(y), y_ref, 1.5e-2)
+    torch.testing.assert_close(stats[..., 0].cpu(), mean_ref, rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(stats[..., 1].cpu(), rstd_ref, rtol=1e-2, atol=1e-3)
+    # and the two-launch path gives the same tensors
+    raw2 = ops.conv_forward(hip.CONV_3X3_S1, x0d, pack.pack_fwd(hip.CONV_3X3_S1, w).to(dev), b.to(dev), co, x1=x1d,
+                            in_add=None if add is None else add.to(dev))
+    y2, stats2 = ops.gn_act_forward(raw2, gamma.to(dev), beta.to(dev), groups, hip.ACT[act], res=None if res is None else nhwc(res, dev))
+    assert torch.equal(raw, raw2)
+    torch.testing.assert_close(stats, stats2, rtol=1e-4, atol=1e-5)
+    assert_rel(y.float().cpu(), y2.float().cpu(), 1e-2)
+    assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, nhwc(r16(hash_normal((2, 64, 8, 8), 69)), dev), None, 64, 16)
