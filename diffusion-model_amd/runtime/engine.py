@@ -154,6 +154,8 @@ class UNetEngine:
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
         self.mask_ahead = False        # keep bits drawn one step ahead by the driver (see _make_masks)
+        self._zero_arena: Optional[Tensor] = None
+        self._zero_cursor = self._zero_need = 0
         self._mask_bufs: Dict = {}
         self._mask_key = None
         self._mask_seed = None
@@ -391,7 +393,7 @@ class UNetEngine:
                 dk = pack.DGRAD_KIND[kind]
                 # gradient of the broadcast add = per-image spatial sum of this conv's own data-gradient,
                 # accumulated in fp32 inside the kernel (x0.g, added afterwards, belongs to other consumers)
-                dsum = torch.zeros(n, c0, device=dev, dtype=torch.float32) if in_add is not None else None
+                dsum = self._take_zeros(n * c0, dev).view(n, c0) if in_add is not None else None
                 x0.g = ops.conv_forward(dk, draw, wd, None, c0, res=x0.g, out_mask=in_mask, out_scale=mscale, rows=c0, sum_out=dsum)
                 if in_add is not None:
                     in_add.g = dsum
@@ -871,6 +873,9 @@ class UNetEngine:
         self._cur_tps = self.wgrad_tiles_last if (marks and phase == len(marks)) else self.wgrad_tiles_per_split
         if phase == 0:
             self.grads.zero()
+            if self._zero_arena is not None:
+                self._zero_arena.zero_()
+            self._zero_cursor = self._zero_need = 0
             out_holder.g = dout
         bounds = [0] + list(marks) + [len(tape)]
         seg = len(bounds) - 2 - phase
@@ -887,7 +892,23 @@ class UNetEngine:
         ready = flush(phase, last)
         if last:
             tape.clear()
+            have = 0 if self._zero_arena is None else self._zero_arena.numel()
+            if self._zero_need > have and not torch.cuda.is_current_stream_capturing():
+                self._zero_arena = torch.empty(self._zero_need, device=self.grads.flat.device, dtype=torch.float32)
         return ready
+
+    def _take_zeros(self, k: int, device) -> Tensor:
+        """k zeroed floats for an accumulator of this backward pass.  They come from one arena cleared by a single fill at
+        the start of the pass (sized by the previous pass; a fill kernel per accumulator costs a launch each: the
+        time-embedding gradients alone need eight per step)."""
+        k64 = (k + 63) // 64 * 64
+        self._zero_need += k64
+        a = self._zero_arena
+        if a is not None and a.device == torch.device(device) and self._zero_cursor + k64 <= a.numel():
+            out = a[self._zero_cursor:self._zero_cursor + k]
+            self._zero_cursor += k64
+            return out
+        return torch.zeros(k, device=device, dtype=torch.float32)
 
     def backward_phase(self, ctx, phase: int, dout: Optional[Tensor] = None) -> bool:
         self.backward_data(ctx, phase, dout)
