@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedFwdArgs a) {
             const bf16 z = (bf16)(acc[r] + b);
             const bf16 y = (bf16)act_fwd((float)z, a.act);
             *(bf16*)(s_h + row * HS + col * 2) = y;
-            if (raw0 && n0 + row < a.N) {
+            if (raw0 && blockIdx.z == 0 && n0 + row < a.N) {
                 raw0[(long long)(n0 + row) * H + col] = z;
                 hs[(long long)(n0 + row) * H + col] = y;
             }
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedFwdArgs a) {
     const bf16* w1 = a.w1[m];
     const float* b1 = a.b1[m];
     float* out = a.out[m];
-    for (int nt = wave; nt < C / 32; nt += 4) {
+    // the second GEMM (K = 2C, its weight rows streamed from L2) is the long part: its column tiles are dealt over the
+    // gridDim.z workgroups of this (row block, MLP), each of which has computed the cheap first GEMM for itself
+    for (int nt = wave + 4 * blockIdx.z; nt < C / 32; nt += 4 * gridDim.z) {
         const int col = nt * 32 + (lane & 31);
         const f32x16 acc = tile_rt(s_h, HS, w1 + (long long)col * H, H, lane);
         const float b = b1[col];
@@ -182,7 +184,7 @@ extern "C" int ddpm_embed_forward(const ddpm_embed_desc* d, ddpm_stream_t stream
     const size_t lds = 32 * (EMB_T * 2 + 16) + 32 * (size_t)(4 * cmax + 16);
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)embed_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ddpm_check_launch("embed_forward: raise dynamic LDS limit");
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3((d->N + 31) / 32, d->nmlp), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((d->N + 31) / 32, d->nmlp, cmax >= 256 ? 8 : cmax >= 128 ? 4 : 1), dim3(256), lds, stream, a);
     return ddpm_check_launch("embed_forward");
 }
 
