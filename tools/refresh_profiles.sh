@@ -1,0 +1,17 @@
+# Runs on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): the bench line, the rocprofv3 kernel statistics of the same
+# command, and the two PMC passes for HBM traffic; condensed results land in gpurun_out/final/ (copy them to profiles/).
+set -e
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/final
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 python3 -u $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -1 $OUT/bench.json | cut -c1-200
+rm -rf /tmp/prof && mkdir -p /tmp/prof
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-sample --no-cpu --no-roofline > $OUT/bench_under_rocprof.json 2> /tmp/prof/stats.err
+python3 $R/tools/profile_summary.py stats /tmp/prof/stats $OUT/kernel_stats.csv
+python3 $R/tools/micro/timeline.py $(find /tmp/prof/stats -name '*kernel_trace.csv' | head -1) > $OUT/timeline.txt
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/fetch -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph > /tmp/prof/fetch.out 2> /tmp/prof/fetch.err
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/write -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph > /tmp/prof/write.out 2> /tmp/prof/write.err
+python3 $R/tools/profile_summary.py traffic /tmp/prof/fetch /tmp/prof/write $OUT/hbm_traffic.json
+ls -la $OUT
