@@ -115,14 +115,14 @@ __device__ __forceinline__ void group_finish(int tid, const float* s_part, float
 
 template <int C, int W, int ACT>
 __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
-    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int E = 2 * C, HW = W * W, IPW = sir_ipw(HW), M = IPW * HW, MR = sir_tile_rows(M);
     constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
     constexpr int NWV = SIR_THREADS / 64;
     using E1 = Ew<E, M>;
     using E3 = Ew<C, M>;
     char* s_x = smem;
-    char* s_e = smem + M * XS;
-    float* s_part = (float*)(s_e + M * ES);       // [slots][2][16] per-wave partial group sums / sums of squares
+    char* s_e = smem + MR * XS;
+    float* s_part = (float*)(s_e + MR * ES);      // [slots][2][16] per-wave partial group sums / sums of squares
     float* s_mr = s_part + SIR_SLOTS * 2 * SIR_G; // [IPW][16][2] mean, rstd
     float* s_p = s_mr + 2 * IPW * SIR_G;          // all per-channel parameters of the block, fetched once
     constexpr int P_BE = 0, P_G1 = E, P_B1 = 2 * E, P_BD = 3 * E, P_G2 = 4 * E, P_B2 = 5 * E, P_WD = 6 * E, P_BP = 15 * E,
@@ -159,7 +159,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         for (int j = 0; j < 8; ++j) rx[k][j] = (bf16)0.f;
         if (row < rows_valid) rx[k] = *(const bf16x8*)(a.x + (row0 + row) * C + v3 * 8);
     }
-    constexpr int MT = M / 32;
+    constexpr int MT = MR / 32;
     bf16x8 bfrag1[GemmK<C>::KCH];                 // first weight chunk of this wave's first expansion tile
     if (wave < MT * (E / 32)) gemm_prefetch<C>(bfrag1, a.we + (long long)((wave / MT) * 32 + (lane & 31)) * C, lane);
 
@@ -648,7 +648,7 @@ static int sir_big_launch(const SirArgs& a, hipStream_t stream) {
 
 template <int C, int W>
 static int sir_launch(const SirArgs& a, hipStream_t stream) {
-    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int E = 2 * C, HW = W * W, IPW = sir_ipw(HW), M = sir_tile_rows(IPW * HW);
     constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) + (SIR_SLOTS * 2 * SIR_G + 2 * IPW * SIR_G + 15 * E + 3 * C) * 4;
     static_assert(IPW == 1 || (Ew<E, M>::NV <= 4 && Ew<C, M>::NV <= 4), "more passes than partial-sum slots");
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");

@@ -199,14 +199,14 @@ __device__ __forceinline__ void col2_flush(const float* s_slot, float* part, lon
 
 template <int C, int W, int ACT>
 __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
-    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int E = 2 * C, HW = W * W, IPW = sir_ipw(HW), M = IPW * HW, MR = sir_tile_rows(M);
     constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
-    constexpr int NWV = SIR_THREADS / 64, MT = M / 32;
+    constexpr int NWV = SIR_THREADS / 64, MT = MR / 32;
     using E1 = Ew<E, M>;
     using E3 = Ew<C, M>;
     char* s_x = smem;                              // [M][XS]  d_o, later the expansion data-gradient
-    char* s_e = s_x + M * XS;                      // [M][ES]  projection data-gradient -> dd -> d_e
-    float* s_col = (float*)(s_e + M * ES);         // [3][waves][E] per-wave column sums
+    char* s_e = s_x + MR * XS;                     // [M][ES]  projection data-gradient -> dd -> d_e
+    float* s_col = (float*)(s_e + MR * ES);        // [3][waves][E] per-wave column sums
     float* s_grp = s_col + 3 * NWV * E;            // [IPW][16][2]
     float* s_mr = s_grp + IPW * 2 * SIR_G;         // [3][IPW][16][2]  mean, rstd of the three norms
     float* s_p = s_mr + 3 * IPW * 2 * SIR_G;       // per-channel parameters
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_bwd_kernel(const SirBwdArgs a
 
 template <int C, int W>
 static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
-    constexpr int E = 2 * C, HW = W * W, IPW = HW >= 32 ? 1 : 32 / HW, M = IPW * HW;
+    constexpr int E = 2 * C, HW = W * W, IPW = sir_ipw(HW), M = sir_tile_rows(IPW * HW);
     constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) +
                         (3 * (SIR_THREADS / 64) * E + IPW * 2 * SIR_G + 3 * IPW * 2 * SIR_G + 13 * E + C) * 4;
     static_assert(lds <= 160 * 1024, "tiles do not fit LDS");
@@ -838,7 +838,7 @@ static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
 }
 
 extern "C" int ddpm_sir_workgroups(int HW, int N) {
-    const int ipw = HW >= 32 ? 1 : 32 / HW;
+    const int ipw = sir_ipw(HW);
     return (N + ipw - 1) / ipw;
 }
 

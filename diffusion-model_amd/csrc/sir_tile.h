@@ -6,6 +6,13 @@ constexpr int SIR_G = 16;            // GroupNorm groups (the reference's base_g
 constexpr int SIR_THREADS = 512;
 constexpr int SIR_SLOTS = 4 * (SIR_THREADS / 64);   // partial-sum slots: up to 4 passes x 8 waves
 
+// Images per workgroup: one for images of >= 32 pixels; small images are batched so that a tile has 32 rows (one MFMA
+// row block), except 2x2 images: four of them (16 rows) - at 256+ channels the elementwise phases, not the half-empty
+// MFMA tile, are what a workgroup spends its time on, and twice as many workgroups share them.
+constexpr int sir_ipw(int hw) { return hw >= 32 ? 1 : (hw == 4 ? 4 : 32 / hw); }
+// Rows the LDS tiles are allocated (and the MFMA tiles computed) for: at least one 32-row block; rows >= M are never read back.
+constexpr int sir_tile_rows(int m) { return m < 32 ? 32 : m; }
+
 template <int ACT>
 __device__ __forceinline__ float act_c(float z) {
     if constexpr (ACT == ACT_GELU) { float c, g; gelu_parts(z, c, g); return z * c; }
