@@ -1,0 +1,112 @@
+// 3x3 stride-1 convolution with very few OUTPUT channels (the UNet's image head: 32 -> 1 or 3 channels, tanh, fp32 NCHW).
+//
+// On the implicit-GEMM kernel such a layer computes a 32-wide MFMA tile to keep one column of it and is bound by the
+// staging of its input; here a thread owns one output pixel, the input patch of a 8 x 32 pixel tile (with halo) sits in
+// LDS, and the 288 (x Cout) multiply-adds per pixel run on the vector ALUs against weights broadcast from LDS.
+// Same operands as ddpm_conv_forward (packed bf16 weights [9][w_rows][Cin], fp32 bias), products of bf16 values
+// accumulated in fp32 like the MFMA path (the summation order differs).
+#include "conv_geom.h"
+#include "ddpm_hip.h"
+
+#define THIN_TH 8
+#define THIN_TW 32
+#define THIN_MAXCO 4
+
+struct ThinArgs {
+    const bf16* in; const bf16* w; const float* bias; float* out;
+    int N, H, W, Cin, Cout, w_rows, act;
+};
+
+__global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int PS = a.Cin * 2 + 16;                                // patch pixel stride in bytes (16 B pad against bank conflicts)
+    constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
+    char* s_patch = smem;                                          // [PH][PW][PS]
+    float* s_w = (float*)(smem + PH * PW * PS);                    // [Cout][9][Cin]
+    const int tid = threadIdx.x;
+    const int tiles_w = (a.W + THIN_TW - 1) / THIN_TW, tiles_h = (a.H + THIN_TH - 1) / THIN_TH;
+    int t = blockIdx.x;
+    const int twi = t % tiles_w; t /= tiles_w;
+    const int thi = t % tiles_h;
+    const int n = t / tiles_h;
+    const int y0 = thi * THIN_TH, x0 = twi * THIN_TW;
+    const int vpp = a.Cin / 8;                                     // 16-byte vectors per pixel
+
+    for (int i = tid; i < a.Cout * 9 * a.Cin; i += 256) {
+        const int co = i / (9 * a.Cin), r = i - co * 9 * a.Cin, tap = r / a.Cin, ci = r - tap * a.Cin;
+        s_w[i] = (float)a.w[((long long)tap * a.w_rows + co) * a.Cin + ci];
+    }
+    const int items = PH * PW * vpp;
+    for (int base = tid; base < items; base += 256 * 6) {
+        bf16x8 v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int it = base + u * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+            if (it < items) {
+                const int p = it / vpp, part = it - p * vpp;
+                const int py = p / PW, px = p - py * PW;
+                const int iy = y0 + py - 1, ix = x0 + px - 1;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    v[u] = *(const bf16x8*)(a.in + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + part * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int it = base + u * 256;
+            if (it < items) {
+                const int p = it / vpp, part = it - p * vpp;
+                *(bf16x8*)(s_patch + p * PS + part * 16) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int ty = tid / THIN_TW, tx = tid % THIN_TW;
+    float acc[THIN_MAXCO];
+#pragma unroll
+    for (int co = 0; co < THIN_MAXCO; ++co) acc[co] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const char* pp = s_patch + ((ty + dy) * PW + tx + dx) * PS;
+        for (int part = 0; part < vpp; ++part) {
+            const bf16x8 xv = *(const bf16x8*)(pp + part * 16);
+            float xf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = (float)xv[j];
+#pragma unroll
+            for (int co = 0; co < THIN_MAXCO; ++co) {
+                if (co < a.Cout) {
+                    const float* wp = s_w + (co * 9 + tap) * a.Cin + part * 8;
+                    const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[co] += xf[j] * w0[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[co] += xf[4 + j] * w1[j];
+                }
+            }
+        }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy < a.H && ox < a.W) {
+#pragma unroll
+        for (int co = 0; co < THIN_MAXCO; ++co)
+            if (co < a.Cout)
+                a.out[(((long long)n * a.Cout + co) * a.H + oy) * a.W + ox] = act_fwd(acc[co] + (a.bias ? a.bias[co] : 0.f), a.act);
+    }
+}
+
+// Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
+int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream) {
+    if (d->kind != CONV_3X3_S1 || d->out_mode != OUT_F32_NCHW || d->Cout > THIN_MAXCO || d->C1 != 0) return 0;
+    if (d->in_add || d->in_mask || d->out_mask || d->res || d->sum_out || d->gn_gamma) return 0;
+    if (d->C0 % 8 || d->C0 > 64) return 0;
+    ThinArgs a;
+    a.in = (const bf16*)d->in0; a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (float*)d->out;
+    a.N = d->N; a.H = d->IH; a.W = d->IW; a.Cin = d->C0; a.Cout = d->Cout; a.w_rows = d->w_rows; a.act = d->act;
+    const size_t lds = (size_t)(THIN_TH + 2) * (THIN_TW + 2) * (d->C0 * 2 + 16) + (size_t)d->Cout * 9 * d->C0 * 4;
+    const long long tiles = (long long)d->N * ((d->IH + THIN_TH - 1) / THIN_TH) * ((d->IW + THIN_TW - 1) / THIN_TW);
+    if (lds > 64 * 1024 || tiles > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(conv_thin_out_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    return ddpm_check_launch("conv_thin") == DDPM_OK ? 1 : -1;
+}

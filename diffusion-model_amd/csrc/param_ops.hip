@@ -20,22 +20,60 @@ __global__ __launch_bounds__(256) void remap_kernel(const ddpm_remap_entry* __re
     const unsigned total = (unsigned)e.S * (unsigned)e.R * (unsigned)e.K;
     const unsigned i0 = (unsigned)ch.y * REMAP_CHUNK;
     const unsigned K = (unsigned)e.K, R = (unsigned)e.R;
-#pragma unroll
-    for (int u = 0; u < REMAP_CHUNK / 256; ++u) {
-        const unsigned i = i0 + u * 256 + threadIdx.x;
-        if (i >= total) break;
-        const unsigned sr = i / K;
-        const int k = (int)(i - sr * K);
-        const int s = (int)(sr / R), r = (int)(sr - (unsigned)s * R);
-        const bool valid = r < e.Rv && k < e.Kv;
-        const int bi = r * e.a_r + k * e.a_k + ep->off_s[s];
-        if (to_a) {
-            const float v = valid ? ((const float*)e.b)[bi] : 0.f;
-            if (e.a_bf16) ((bf16*)e.a)[i] = (bf16)v;
-            else ((float*)e.a)[i] = v;
-        } else if (valid) {
-            ((float*)e.b)[bi] = e.a_bf16 ? (float)((const bf16*)e.a)[i] : ((const float*)e.a)[i];
+    // eight consecutive k per thread where K is a multiple of 8 (A's base is 16-byte aligned: weight copies are tensors of
+    // their own, gradient slots start at multiples of 4 floats): the index arithmetic is paid once per 8 elements and A is
+    // moved as one 16- or 32-byte vector
+    const unsigned i = i0 + threadIdx.x * 8;
+    if (i >= total) return;
+    if (K % 8) {                                   // small odd-sized tensors (a 1- or 3-channel bias): element by element
+        for (unsigned q = i; q < i + 8 && q < total; ++q) {
+            const unsigned sr = q / K;
+            const int k = (int)(q - sr * K);
+            const int s = (int)(sr / R), r = (int)(sr - (unsigned)s * R);
+            const bool valid = r < e.Rv && k < e.Kv;
+            const int bi = r * e.a_r + k * e.a_k + ep->off_s[s];
+            if (to_a) {
+                const float v = valid ? ((const float*)e.b)[bi] : 0.f;
+                if (e.a_bf16) ((bf16*)e.a)[q] = (bf16)v;
+                else ((float*)e.a)[q] = v;
+            } else if (valid) {
+                ((float*)e.b)[bi] = e.a_bf16 ? (float)((const bf16*)e.a)[q] : ((const float*)e.a)[q];
+            }
         }
+        return;
+    }
+    const unsigned sr = i / K;
+    const int k0 = (int)(i - sr * K);
+    const int s = (int)(sr / R), r = (int)(sr - (unsigned)s * R);
+    const int bi = r * e.a_r + k0 * e.a_k + ep->off_s[s];
+    float* const b = (float*)e.b;
+    if (to_a) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (r < e.Rv && k0 + j < e.Kv) ? b[bi + j * e.a_k] : 0.f;
+        if (e.a_bf16) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+            *(bf16x8*)((bf16*)e.a + i) = o;
+        } else {
+            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *(f32x4*)((float*)e.a + i) = o0; *(f32x4*)((float*)e.a + i + 4) = o1;
+        }
+    } else if (r < e.Rv) {
+        float v[8];
+        if (e.a_bf16) {
+            const bf16x8 x = *(const bf16x8*)((const bf16*)e.a + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+        } else {
+            const f32x4 x0 = *(const f32x4*)((const float*)e.a + i), x1 = *(const f32x4*)((const float*)e.a + i + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < e.Kv) b[bi + j * e.a_k] = v[j];
     }
 }
 

@@ -104,9 +104,10 @@ def test_conv_fused_input_and_epilogue(dev):
     assert_rel(nchw(y), ref, 1.5e-2)
 
 
-def test_conv_head_f32_nchw_tanh(dev):
-    n, ci, co, h = 2, 32, 3, 16
-    x = r16(hash_normal((n, ci, h, h), 1))
+@pytest.mark.parametrize("n,ci,co,h,wd", [(2, 32, 3, 16, 16), (3, 32, 1, 32, 32), (1, 32, 3, 20, 72), (2, 64, 4, 8, 40), (1, 32, 1, 128, 128)])
+def test_conv_head_f32_nchw_tanh(dev, n, ci, co, h, wd):
+    """the image head (few output channels, tanh, fp32 NCHW): the vector-ALU kernel, ragged tiles included"""
+    x = r16(hash_normal((n, ci, h, wd), 1))
     w = r16(hash_normal((co, ci, 3, 3), 2) * 0.06)
     b = hash_normal((co,), 3) * 0.1
     ref = torch.tanh(F.conv2d(x, w, b, padding=1))
