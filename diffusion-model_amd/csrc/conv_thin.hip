@@ -96,8 +96,92 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
     }
 }
 
+// The mirror case: very few INPUT channels that matter (the stem: the image's 1 or 3 channels, stored zero-padded to 16;
+// and the head's data-gradient, whose input is the gradient of those channels), 32 output channels.  A thread owns one
+// pixel and its 32 accumulators; the patch keeps only the channels the caller declares as used (C0_used).
+struct ThinInArgs {
+    const bf16* in; const bf16* w; const float* bias; bf16* out;
+    int N, H, W, Cin, Cused, Cout, out_cs, w_rows, act;
+};
+
+__global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
+    constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
+    __shared__ __attribute__((aligned(16))) bf16 s_patch[PH * PW][4];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 4 * 32];             // [tap][ci][co]
+    const int tid = threadIdx.x;
+    const int tiles_w = (a.W + THIN_TW - 1) / THIN_TW, tiles_h = (a.H + THIN_TH - 1) / THIN_TH;
+    int t = blockIdx.x;
+    const int twi = t % tiles_w; t /= tiles_w;
+    const int thi = t % tiles_h;
+    const int n = t / tiles_h;
+    const int y0 = thi * THIN_TH, x0 = twi * THIN_TW;
+    for (int i = tid; i < 9 * 4 * 32; i += 256) {
+        const int tap = i / 128, r = i - tap * 128, ci = r / 32, co = r - ci * 32;
+        s_w[i] = (ci < a.Cused && co < a.Cout) ? (float)a.w[((long long)tap * a.w_rows + co) * a.Cin + ci] : 0.f;
+    }
+    for (int p = tid; p < PH * PW; p += 256) {
+        const int py = p / PW, px = p - py * PW;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        bf16x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (bf16)0.f;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const bf16x4*)(a.in + (((long long)n * a.H + iy) * a.W + ix) * a.Cin);
+        *(bf16x4*)s_patch[p] = v;
+    }
+    __syncthreads();
+    const int ty = tid / THIN_TW, tx = tid % THIN_TW;
+    float acc[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const bf16x4 xv = *(const bf16x4*)s_patch[(ty + dy) * PW + tx + dx];
+        for (int ci = 0; ci < a.Cused; ++ci) {
+            const float x = (float)xv[ci];
+            const float* wp = s_w + (tap * 4 + ci) * 32;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 w4 = *(const f32x4*)(wp + q * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q * 4 + j] += x * w4[j];
+            }
+        }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy < a.H && ox < a.W) {
+        bf16* op = a.out + (((long long)n * a.H + oy) * a.W + ox) * a.out_cs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = q * 8 + j;
+                o[j] = (bf16)act_fwd(acc[co] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
+            }
+            if (q * 8 + 8 <= a.Cout) *(bf16x8*)(op + q * 8) = o;
+            else
+                for (int j = 0; j < a.Cout - q * 8; ++j) op[q * 8 + j] = o[j];
+        }
+    }
+}
+
+static int conv_thin_in_try(const ddpm_conv_desc* d, hipStream_t stream) {
+    if (d->kind != CONV_3X3_S1 || d->out_mode != OUT_BF16_NHWC || d->C1 != 0 || d->C0_used < 1 || d->C0_used > 4) return 0;
+    if (d->in_add || d->in_mask || d->out_mask || d->res || d->sum_out || d->gn_gamma) return 0;
+    if (d->C0 % 4 || d->Cout > 32 || d->CoutW != 32 || d->out_cs % 8) return 0;
+    ThinInArgs a;
+    a.in = (const bf16*)d->in0; a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out;
+    a.N = d->N; a.H = d->IH; a.W = d->IW; a.Cin = d->C0; a.Cused = d->C0_used; a.Cout = d->Cout; a.out_cs = d->out_cs;
+    a.w_rows = d->w_rows; a.act = d->act;
+    const long long tiles = (long long)d->N * ((d->IH + THIN_TH - 1) / THIN_TH) * ((d->IW + THIN_TW - 1) / THIN_TW);
+    if (tiles > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(conv_thin_in_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    return ddpm_check_launch("conv_thin_in") == DDPM_OK ? 1 : -1;
+}
+
 // Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
 int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream) {
+    if (const int rc = conv_thin_in_try(d, stream)) return rc;
     if (d->kind != CONV_3X3_S1 || d->out_mode != OUT_F32_NCHW || d->Cout > THIN_MAXCO || d->C1 != 0) return 0;
     if (d->in_add || d->in_mask || d->out_mask || d->res || d->sum_out || d->gn_gamma) return 0;
     if (d->C0 % 8 || d->C0 > 64) return 0;

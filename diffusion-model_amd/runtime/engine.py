@@ -342,8 +342,10 @@ class UNetEngine:
 
         # ---- fused units ------------------------------------------------------------------------
         def conv_unit(name: str, x0: Var, *, x1: Optional[Var] = None, in_add: Optional[Var] = None, in_mask=None,
-                      norm: Optional[str] = None, groups: int = 0, act: int = 0, res: Optional[Var] = None, out_mask=None) -> Var:
-            """conv [-> GroupNorm] -> act [-> * out_mask] [+ res].  `norm` = parameter prefix of the GroupNorm."""
+                      norm: Optional[str] = None, groups: int = 0, act: int = 0, res: Optional[Var] = None, out_mask=None,
+                      c0_used: int = 0) -> Var:
+            """conv [-> GroupNorm] -> act [-> * out_mask] [+ res].  `norm` = parameter prefix of the GroupNorm.
+            c0_used: only that many leading channels of x0 are non-zero (the zero-padded image at the stem)."""
             kind = sp.convs[name]
             wf = wc.fwd[name]
             bias = P[name + ".bias"]
@@ -351,7 +353,7 @@ class UNetEngine:
             if norm is None and tape is None and res is None and out_mask is None:
                 # inference, no normalisation: the activation runs in the convolution's epilogue (no pre-activation is kept)
                 return Var(ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
-                                            in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act=act))
+                                            in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act=act, c0_used=c0_used))
             gamma = P[norm + ".weight"] if norm else None
             beta = P[norm + ".bias"] if norm else None
             if norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
@@ -361,7 +363,7 @@ class UNetEngine:
                                                  gn=(gamma, beta, groups, act, None if res is None else res.v))
             else:
                 raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
-                                       in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale)
+                                       in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, c0_used=c0_used)
                 y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
                                               mask=out_mask, mask_scale=mscale)
             out = Var(y)
@@ -701,7 +703,7 @@ class UNetEngine:
                             wgrad(K11, sin, dz_, 2 * ewidths[i], enames[i] + "layers.0")
                     return run
                 embed_bwd_factory = bwd_embed
-        z = conv_unit(e + "stem_layers.0", Var(xin, need_grad=False), act=sp.act)
+        z = conv_unit(e + "stem_layers.0", Var(xin, need_grad=False), act=sp.act, c0_used=c_img if c_img <= 4 else 0)
         tap("enc.stem", z.v)
         skips: List[Var] = []
         marks: List[int] = []                           # tape positions where a backward phase ends (forward order)
@@ -759,7 +761,7 @@ class UNetEngine:
                 hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, 16, hip.stream())
                 ops.colsum(dz, G[name + ".bias"], c_img)
                 wgrad(K33, hfeat.v, dz, c_img, name)
-                hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3])
+                hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3], c0_used=c_img if c_img <= 4 else 0)
             tape.append(bwd_head)
             if embed_bwd_factory is not None:
                 # an MLP's backward belongs to the phase that back-propagates its stage

@@ -123,6 +123,9 @@ typedef struct ddpm_conv_desc {
     void* gn_out; float* gn_stats; const void* gn_res;
     int gn_groups, gn_act;
     float gn_eps;
+    int C0_used;               /* 0, or a promise that only the first C0_used (1..4) channels of in0 are non-zero (an image stored
+                                * zero-padded to 16 channels: the stem, and the head's data-gradient): lets a 3x3 convolution to 32
+                                * channels run on a kernel that reads only those. */
 } ddpm_conv_desc;
 int ddpm_conv_gn_fusable(const ddpm_conv_desc* d);
 

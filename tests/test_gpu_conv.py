@@ -166,3 +166,21 @@ def test_conv_with_fused_groupnorm(dev, n, ci, c1, co, hw, groups, act, with_res
     torch.testing.assert_close(stats, stats2, rtol=1e-4, atol=1e-5)
     assert_rel(y.float().cpu(), y2.float().cpu(), 1e-2)
     assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, nhwc(r16(hash_normal((2, 64, 8, 8), 69)), dev), None, 64, 16)
+
+
+@pytest.mark.parametrize("n,c_used,co,h,wd,act", [(3, 1, 32, 32, 32, "gelu"), (2, 3, 32, 20, 72, "none"), (1, 3, 32, 64, 64, "silu"), (2, 4, 24, 8, 8, "none")])
+def test_conv_thin_input(dev, n, c_used, co, h, wd, act):
+    """3x3 convolution of a zero-padded image tensor (16 stored channels, c_used real ones) to 32 channels: the stem and
+    the head's data-gradient, on the vector-ALU kernel (C0_used promise) - against torch and against the general kernel."""
+    from oracle import ref_cpu as O
+    x = r16(hash_normal((n, c_used, h, wd), 71))
+    w = r16(hash_normal((co, c_used, 3, 3), 72) * 0.3)
+    b = hash_normal((co,), 73) * 0.1
+    f = O.act_fn(act) if act != "none" else (lambda t: t)
+    ref = f(F.conv2d(x, w, b, padding=1))
+    w16 = torch.zeros(co, 16, 3, 3); w16[:, :c_used] = w
+    xd, wp = nhwc(x, dev, cpad=16), pack.pack_fwd(hip.CONV_3X3_S1, w16).to(dev)
+    y = ops.conv_forward(hip.CONV_3X3_S1, xd, wp, b.to(dev), co, act=hip.ACT[act], c0_used=c_used, out_cs=32)
+    y0 = ops.conv_forward(hip.CONV_3X3_S1, xd, wp, b.to(dev), co, act=hip.ACT[act], out_cs=32)
+    assert_rel(nchw(y[..., :co]), ref)
+    assert_rel(y[..., :co].float().cpu(), y0[..., :co].float().cpu(), 1e-2)
