@@ -29,6 +29,8 @@ struct ConvArgs {
     int Cout, CoutW, out_cs, w_rows; // real output channels; rows computed; channel stride of out; rows per weight slice
     int act, out_mode;
     float* sum_out;                  // optional fp32 [N][Cout] per-image sums of the activated output (atomics)
+    bf16* out2; int act2;            // optional second result act2(out), same layout: a unit without normalisation keeps its
+                                     // pre-activation for the backward pass and hands the activated tensor on
 };
 
 // Loads are issued in batches of STAGE_U per thread before any of them is consumed, so that each thread keeps
@@ -297,6 +299,12 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
         } else {
             for (int j = 0; j < a.Cout - co; ++j) out[e + j] = v[j];
         }
+        if (a.out2) {                  // Cout % 8 == 0 (host-checked)
+            bf16x8 y;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)v[j], a.act2);
+            *(bf16x8*)(a.out2 + e) = y;
+        }
     }
     CONV_STAMP(7);
 }
@@ -362,6 +370,8 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = d->out; a.res = (const bf16*)d->res;
     a.out_mask = d->out_mask; a.out_mask_scale = d->out_mask_scale;
     a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.out_mode = d->out_mode; a.sum_out = d->sum_out;
+    a.out2 = (bf16*)d->out2; a.act2 = d->act2;
+    DDPM_REQUIRE(!d->out2 || (d->out_mode == OUT_BF16_NHWC && d->Cout % 8 == 0 && d->act == 0), "conv: the second (activated) result needs an NHWC bf16 output, Cout %% 8 == 0 and no first activation");
 
     const int npix = a.g.NB * a.g.PH * a.g.PW;
     const int bm = 32 * cfg.wm, bn = 32 * cfg.nt * cfg.wn;

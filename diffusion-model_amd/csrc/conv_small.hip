@@ -215,6 +215,7 @@ extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
 int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     if (d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4)) return 0;
     if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask) return 0;
+    if (d->out2) return 0;
     const int Cin = d->C0 + d->C1;
     if (Cin % 64 || Cin > 512 || d->C0 % 8 || d->C1 % 8 || d->out_cs % 4) return 0;
     SmallConvArgs a;

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
 // and the head's data-gradient, whose input is the gradient of those channels), 32 output channels.  A thread owns one
 // pixel and its 32 accumulators; the patch keeps only the channels the caller declares as used (C0_used).
 struct ThinInArgs {
-    const bf16* in; const bf16* w; const float* bias; bf16* out;
-    int N, H, W, Cin, Cused, Cout, out_cs, w_rows, act;
+    const bf16* in; const bf16* w; const float* bias; bf16* out; bf16* out2;
+    int N, H, W, Cin, Cused, Cout, out_cs, w_rows, act, act2;
 };
 
 __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
@@ -161,6 +161,12 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
             if (q * 8 + 8 <= a.Cout) *(bf16x8*)(op + q * 8) = o;
             else
                 for (int j = 0; j < a.Cout - q * 8; ++j) op[q * 8 + j] = o[j];
+            if (a.out2 && q * 8 + 8 <= a.Cout) {          // second result: act2 of the (bf16) first one, Cout % 8 == 0
+                bf16x8 y;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], a.act2);
+                *(bf16x8*)(a.out2 + (op - a.out) + q * 8) = y;
+            }
         }
     }
 }
@@ -168,11 +174,12 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
 static int conv_thin_in_try(const ddpm_conv_desc* d, hipStream_t stream) {
     if (d->kind != CONV_3X3_S1 || d->out_mode != OUT_BF16_NHWC || d->C1 != 0 || d->C0_used < 1 || d->C0_used > 4) return 0;
     if (d->in_add || d->in_mask || d->out_mask || d->res || d->sum_out || d->gn_gamma) return 0;
+    if (d->out2 && (d->Cout % 8 || d->act != 0)) return 0;
     if (d->C0 % 4 || d->Cout > 32 || d->CoutW != 32 || d->out_cs % 8) return 0;
     ThinInArgs a;
     a.in = (const bf16*)d->in0; a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out;
     a.N = d->N; a.H = d->IH; a.W = d->IW; a.Cin = d->C0; a.Cused = d->C0_used; a.Cout = d->Cout; a.out_cs = d->out_cs;
-    a.w_rows = d->w_rows; a.act = d->act;
+    a.w_rows = d->w_rows; a.act = d->act; a.out2 = (bf16*)d->out2; a.act2 = d->act2;
     const long long tiles = (long long)d->N * ((d->IH + THIN_TH - 1) / THIN_TH) * ((d->IW + THIN_TW - 1) / THIN_TW);
     if (tiles > 0x7fffffffll) return 0;
     hipLaunchKernelGGL(conv_thin_in_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);

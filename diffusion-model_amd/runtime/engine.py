@@ -361,6 +361,13 @@ class UNetEngine:
                 raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                                  in_add=None if in_add is None else in_add.v,
                                                  gn=(gamma, beta, groups, act, None if res is None else res.v))
+            elif norm is None and res is None and out_mask is None and cout % 8 == 0 and x0.v.shape[1] > 4:
+                # no normalisation: the activated tensor is a second result of the convolution's launch (the pre-activation
+                # stays for the backward pass)
+                raw, y = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
+                                          in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act2=act,
+                                          c0_used=c0_used)
+                stats = None
             else:
                 raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                        in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, c0_used=c0_used)

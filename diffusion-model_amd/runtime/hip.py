@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("Cout", _i), ("CoutW", _i), ("out_cs", _i), ("w_rows", _i),
         ("act", _i), ("out_mode", _i), ("sum_out", _vp),
         ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_stats", _vp), ("gn_res", _vp),
-        ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("C0_used", _i),
+        ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("out2", _vp), ("act2", _i), ("C0_used", _i),
     ]
 
 

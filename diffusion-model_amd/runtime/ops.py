@@ -49,10 +49,11 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                  in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0, act: int = 0,
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
                  out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
-                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0):
+                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None):
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
     (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
     sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res.
+    act2: also return act2(result) as a second tensor (the result itself without activation): returns (raw, y).
     c0_used: promise that only the first c0_used (1..4) channels of x0 are non-zero (zero-padded image tensors).
     gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
     where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone."""
@@ -73,6 +74,9 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out), C0_used=c0_used)
     y = stats = None
+    if act2 is not None:
+        y = torch.empty_like(out)
+        d.out2, d.act2 = hip.ptr(y), act2
     if gn is not None:
         gamma, beta, groups, gact, gres = gn
         y = torch.empty(n, oh, ow, cout, device=x0.device, dtype=BF16)
@@ -88,6 +92,8 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                 2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}")
 
     _launch("conv_mfma_kernel", cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
+    if act2 is not None:
+        return out, y
     return out if gn is None else (out, y, stats)
 
 

@@ -123,6 +123,8 @@ typedef struct ddpm_conv_desc {
     void* gn_out; float* gn_stats; const void* gn_res;
     int gn_groups, gn_act;
     float gn_eps;
+    void* out2; int act2;      /* optional second NHWC bf16 result act2(out) (out itself without activation): a conv -> act unit keeps
+                                * the pre-activation for its backward pass and hands the activated tensor on, in one launch */
     int C0_used;               /* 0, or a promise that only the first C0_used (1..4) channels of in0 are non-zero (an image stored
                                 * zero-padded to 16 channels: the stem, and the head's data-gradient): lets a 3x3 convolution to 32
                                 * channels run on a kernel that reads only those. */

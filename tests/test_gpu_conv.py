@@ -184,3 +184,21 @@ def test_conv_thin_input(dev, n, c_used, co, h, wd, act):
     y0 = ops.conv_forward(hip.CONV_3X3_S1, xd, wp, b.to(dev), co, act=hip.ACT[act], out_cs=32)
     assert_rel(nchw(y[..., :co]), ref)
     assert_rel(y[..., :co].float().cpu(), y0[..., :co].float().cpu(), 1e-2)
+
+
+def test_conv_second_activated_result(dev):
+    """conv -> act units without normalisation: raw and act(raw) from one launch (general kernel and thin-input kernel),
+    identical to the raw result of a plain launch and to the activation of its bf16 values."""
+    from oracle import ref_cpu as O
+    for ci, c_used, h in [(32, 0, 32), (16, 1, 32), (16, 3, 16)]:
+        x = r16(hash_normal((2, ci, h, h), 81))
+        if c_used:
+            x[:, c_used:] = 0
+        w = r16(hash_normal((32, ci, 3, 3), 82) * 0.1)
+        b = hash_normal((32,), 83) * 0.1
+        xd, wp = nhwc(x, dev), pack.pack_fwd(hip.CONV_3X3_S1, w).to(dev)
+        raw, y = ops.conv_forward(hip.CONV_3X3_S1, xd, wp, b.to(dev), 32, act2=hip.ACT["gelu"], c0_used=c_used)
+        raw0 = ops.conv_forward(hip.CONV_3X3_S1, xd, wp, b.to(dev), 32, c0_used=c_used)
+        assert torch.equal(raw, raw0)
+        assert_rel(nchw(raw), F.conv2d(x, w, b, padding=1))
+        assert_rel(y.float().cpu(), O.act_fn("gelu")(raw.float().cpu()), 1e-2)
