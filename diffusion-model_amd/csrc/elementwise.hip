@@ -302,6 +302,54 @@ extern "C" int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int 
 }
 
 // Advance a device-resident 64-bit seed by one (so a replayed graph draws fresh randomness each step).
+// Backward of a bare activation between a convolution and its consumer (conv -> act units without normalisation, e.g. the
+// stem, conv_block.py:19-54 there with norm = None): dx = dy * act'(x), plus the column sums of dx (the convolution's
+// bias gradient) as one partial row per workgroup: part[(n * P + p)][C], image n cut into P pixel ranges.  Many
+// workgroups per image: the tensors of these units are the largest of the network and the work is pure streaming.
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                                                       float* __restrict__ part, int HW, int C, int P, int act) {
+    __shared__ float s_red[4 * 64];
+    const int tid = threadIdx.x;
+    const int vps = C / 8;                           // power of two <= 8 (host-checked)
+    const int n = blockIdx.x / P, p = blockIdx.x - n * P;
+    const int rows = HW / P;
+    const int cv = tid % vps, prow = tid / vps, pstep = 256 / vps;
+    const long long base = ((long long)n * HW + (long long)p * rows) * C + cv * 8;
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+#pragma unroll 4
+    for (int r = prow; r < rows; r += pstep) {
+        const long long e = base + (long long)r * C;
+        const bf16x8 xv = *(const bf16x8*)(x + e), dv = *(const bf16x8*)(dy + e);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = (float)dv[j] * act_bwd((float)xv[j], act);
+            sum[j] += d;
+            o[j] = (bf16)d;
+        }
+        *(bf16x8*)(dx + e) = o;
+    }
+    block_reduce_cols<256>(sum, vps, s_red, tid);
+    if (tid < vps) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[(long long)blockIdx.x * C + tid * 8 + j] = sum[j];
+    }
+}
+
+extern "C" int ddpm_act_backward(const void* x, const void* dy, void* dx, float* part, int N, int HW, int C, int P, int act,
+                                 ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && dy && dx && part && N > 0 && HW > 0, "act_backward: bad arguments");
+    DDPM_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "act_backward: C must be 8, 16, 32 or 64 (got %d)", C);
+    DDPM_REQUIRE(P > 0 && HW % P == 0 && (long long)N * P < (1ll << 31), "act_backward: P (%d) must divide H*W (%d)", P, HW);
+    DDPM_REQUIRE(act >= 0 && act <= ACT_LAST, "act_backward: unknown activation %d", act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(N * P)), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, (bf16*)dx, part, HW,
+                       C, P, act);
+    return ddpm_check_launch("act_backward");
+}
+
 // t ~ U{1..T} per image (base_trainer.py:202 there draws it with torch.randint): Philox word i of the (seed, stream) sequence,
 // mapped to the range by multiply-high.  Drawing it here keeps the framework's generator (and the bookkeeping kernels
 // a captured graph needs for it) out of the training step.

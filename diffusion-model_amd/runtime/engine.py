@@ -390,8 +390,16 @@ class UNetEngine:
                 if res is not None:                       # residual input receives the same gradient (no copy)
                     assert res.g is None
                     res.g = dy
-                draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
-                                           gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
+                splits = ops.act_backward_splits(raw) if (norm is None and out_mask is None) else 0
+                if splits:
+                    # bare activation: a streaming kernel with many workgroups per image; its partial bias-gradient rows
+                    # are folded with all the others
+                    buf, off = part_alloc(n * splits * cout)
+                    part_entries.append((off, G.offset(name + ".bias"), n * splits, cout, cout))
+                    draw = ops.act_backward(raw, dy, act, buf, splits)
+                else:
+                    draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
+                                               gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
                 out.g = None
                 wgrad(kind, x0.v, draw, cout, name, x1=None if x1 is None else x1.v,
                       in_add=None if in_add is None else in_add.v, in_mask=in_mask)

@@ -111,6 +111,7 @@ _PROTOS = {
     "ddpm_tanh_bwd_nchw_to_nhwc": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_bump_seed": ([_vp, _vp], _i),
     "ddpm_sample_timesteps": ([_vp, _i, _i, _vp, _u32, _vp], _i),
+    "ddpm_act_backward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "ddpm_prepare_images": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
     "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),

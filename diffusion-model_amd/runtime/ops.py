@@ -200,6 +200,28 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
     return out
 
 
+def act_backward_splits(x: Tensor) -> int:
+    """Pixel ranges per image for act_backward (0: shape not supported, use gn_act_backward with groups = 0)."""
+    n, h, w, c = x.shape
+    if c not in (8, 16, 32, 64):
+        return 0
+    p = 1
+    while (h * w) % (2 * p) == 0 and h * w * c // (8 * p) > 1024 and p < 64:      # ~4 vectors per thread
+        p *= 2
+    return p
+
+
+def act_backward(x: Tensor, dy: Tensor, act: int, part: Tensor, splits: int) -> Tensor:
+    """dx = dy * act'(x); part: fp32 [N * splits][C] receives the column sums of dx per pixel range."""
+    n, h, w, c = x.shape
+    assert dy.shape == x.shape and dy.dtype == BF16 and dy.is_contiguous() and x.is_contiguous()
+    assert part.dtype == torch.float32 and part.numel() == n * splits * c
+    out = torch.empty_like(x)
+    _launch("act_bwd_kernel", lambda: (_nb(x, dy, out, part), 0.0, f"{h}x{w} C{c} a{act}"),
+            lambda: hip.call("ddpm_act_backward", hip.ptr(x), hip.ptr(dy), hip.ptr(out), hip.ptr(part), n, h * w, c, splits, act, hip.stream()))
+    return out
+
+
 def _ptr_array(tensors):
     arr = (C.c_void_p * hip.EMBED_MAX)()
     for i, t in enumerate(tensors):

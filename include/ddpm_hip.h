@@ -78,6 +78,10 @@ int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int C, int HW, 
 int ddpm_tanh_bwd_nchw_to_nhwc(const float* dy, const float* y, void* dz, int N, int C, int HW, int cpad, ddpm_stream_t stream);
 /* *seed += odd constant: lets a replayed HIP graph draw fresh randomness every step. */
 int ddpm_bump_seed(uint64_t* seed, ddpm_stream_t stream);
+/* Backward of the bare activation of a conv -> act unit without normalisation (conv_block.py:19-54 with norm = None):
+ * dx = dy * act'(x) on NHWC bf16 [N][HW][C] (C = 8, 16, 32 or 64), and part[(n * P + p)][C] = column sums of dx over the
+ * p-th of P equal pixel ranges of image n (partial rows of the convolution's bias gradient; P must divide HW). */
+int ddpm_act_backward(const void* x, const void* dy, void* dx, float* part, int N, int HW, int C, int P, int act, ddpm_stream_t stream);
 /* t[i] ~ U{1..T}, the per-image training timestep (base_trainer.py:202: torch.randint(1, T + 1, (N,))): Philox4x32-10
  * word i of the (*seed, stream_id) sequence mapped to the range by multiply-high.  t: device int64 [N]. */
 int ddpm_sample_timesteps(int64_t* t, int N, int T, const uint64_t* seed, uint32_t stream_id, ddpm_stream_t stream);

@@ -168,3 +168,27 @@ def test_small_reductions_and_masks(dev):
     hip.call("ddpm_bump_seed", hip.ptr(seed), hip.stream())
     hip.call("ddpm_dropout_masks", hip.ptr(m2), hip.ptr(offs), 3, sum(sizes), 0.9, hip.ptr(seed), hip.stream())
     assert not torch.equal(m1, m2)
+
+
+@pytest.mark.parametrize("n,h,w,c,act", [(3, 32, 32, 32, "gelu"), (2, 16, 16, 64, "silu"), (2, 6, 10, 16, "relu"), (1, 64, 64, 32, "gelu")])
+def test_act_backward_streaming(dev, n, h, w, c, act):
+    """dx = dy * act'(x) and its per-range column sums (the bare activation of a conv -> act unit), against torch fp32 and
+    against the GroupNorm kernel's groups = 0 path.  Tolerance 1e-2 of the scale (bf16 result), sums 1e-3."""
+    from oracle import ref_cpu as O
+    from oracle.noise import hash_normal
+    x = hash_normal((n, h, w, c), 91).bfloat16()
+    dy = hash_normal((n, h, w, c), 92).bfloat16()
+    xl = x.float().requires_grad_(True)
+    O.act_fn(act)(xl).backward(dy.float())
+    xd, dyd = x.to(dev), dy.to(dev)
+    p = ops.act_backward_splits(xd)
+    assert p >= 1 and (h * w) % p == 0
+    part = torch.full((n * p, c), float("nan"), device=dev)
+    dx = ops.act_backward(xd, dyd, hip.ACT[act], part, p)
+    scale = xl.grad.abs().max().item()
+    assert (dx.float().cpu() - xl.grad).abs().max().item() <= 1e-2 * scale
+    torch.testing.assert_close(part.view(n, p, c).sum(1).cpu(), xl.grad.sum((1, 2)), rtol=1e-3, atol=1e-3 * h * w ** 0.5)
+    part3 = torch.zeros(n, 3, c, device=dev)
+    dx0 = ops.gn_act_backward(xd, dyd, None, None, 0, hip.ACT[act], None, part3)
+    assert torch.equal(dx, dx0)
+    assert ops.act_backward_splits(torch.empty(1, 4, 4, 128, device=dev, dtype=torch.bfloat16)) == 0
