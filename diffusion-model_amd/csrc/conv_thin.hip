@@ -147,26 +147,35 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
             }
         }
     }
-    const int oy = y0 + ty, ox = x0 + tx;
-    if (oy < a.H && ox < a.W) {
-        bf16* op = a.out + (((long long)n * a.H + oy) * a.W + ox) * a.out_cs;
+    // results through LDS, so that consecutive lanes store consecutive 16-byte pieces (a thread's own 64 bytes, stored
+    // directly, would make every store instruction touch 64 different lines)
+    __shared__ __attribute__((aligned(16))) char s_out[256 * 80];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bf16x8 o;
+    for (int q = 0; q < 4; ++q) {
+        bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int co = q * 8 + j;
-                o[j] = (bf16)act_fwd(acc[co] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
-            }
-            if (q * 8 + 8 <= a.Cout) *(bf16x8*)(op + q * 8) = o;
-            else
-                for (int j = 0; j < a.Cout - q * 8; ++j) op[q * 8 + j] = o[j];
-            if (a.out2 && q * 8 + 8 <= a.Cout) {          // second result: act2 of the (bf16) first one, Cout % 8 == 0
-                bf16x8 y;
+        for (int j = 0; j < 8; ++j) {
+            const int co = q * 8 + j;
+            o[j] = (bf16)act_fwd(acc[co] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
+        }
+        *(bf16x8*)(s_out + tid * 80 + q * 16) = o;
+    }
+    __syncthreads();
 #pragma unroll
-                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], a.act2);
-                *(bf16x8*)(a.out2 + (op - a.out) + q * 8) = y;
-            }
+    for (int k = 0; k < 4; ++k) {
+        const int it = tid + k * 256, px = it >> 2, q = it & 3;
+        const int oy = y0 + px / THIN_TW, ox = x0 + px % THIN_TW;
+        if (oy >= a.H || ox >= a.W) continue;
+        const bf16x8 o = *(const bf16x8*)(s_out + px * 80 + q * 16);
+        const long long e = (((long long)n * a.H + oy) * a.W + ox) * a.out_cs + q * 8;
+        if (q * 8 + 8 <= a.Cout) *(bf16x8*)(a.out + e) = o;
+        else
+            for (int j = 0; j < a.Cout - q * 8; ++j) a.out[e + j] = o[j];
+        if (a.out2 && q * 8 + 8 <= a.Cout) {              // second result: act2 of the (bf16) first one, Cout % 8 == 0
+            bf16x8 y;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], a.act2);
+            *(bf16x8*)(a.out2 + e) = y;
         }
     }
 }
