@@ -26,7 +26,9 @@ struct SmallConvArgs {
     int gn_groups, gn_act; float gn_eps;
 };
 
-template <int W>
+// KS = MFMA k-steps per wave and tap (Cin = 64 * KS).  The weight fragments of a whole group of taps are requested at once
+// (all nine for KS <= 4, three at a time - double buffered - for KS = 8): one L2 round trip per group instead of one per tap.
+template <int W, int KS>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) {
     constexpr int HW = W * W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
     }
 
     // ---- this wave's quarter of the input channels, all nine taps
-    const int kq = Cin / 4;                            // channels per wave (multiple of 16)
-    const int ksteps = kq / 16;                        // <= 8
+    constexpr int kq = 16 * KS;                        // channels per wave
+    constexpr int TG = KS <= 4 ? 9 : 3, NG = 9 / TG;   // taps per group, groups
     const int r = lane & 31;
     const int p = r % HW, py = p / W, px = p % W;
     const bf16* wbase = a.w + ((long long)(co0 + r) * Cin + wave * kq + (lane >> 5) * 8);
@@ -71,30 +73,33 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    bf16x8 bcur[8], bnext[8];
+    bf16x8 bw[NG > 1 ? 2 : 1][TG][KS];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        if (u < ksteps) bcur[u] = *(const bf16x8*)(wbase + u * 16);
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int u = 0; u < KS; ++u) bw[0][t][u] = *(const bf16x8*)(wbase + t * slice + u * 16);
     __syncthreads();
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap < 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < ksteps) bnext[u] = *(const bf16x8*)(wbase + (tap + 1) * slice + u * 16);
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int u = 0; u < KS; ++u) bw[(g + 1) & 1][t][u] = *(const bf16x8*)(wbase + ((g + 1) * TG + t) * slice + u * 16);
         }
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int ny = py + dy, nx = px + dx;
-        const int nrow = (ny >= 0 && ny < W && nx >= 0 && nx < W) ? r + dy * W + dx : 32;
-        const char* ap = s_a + nrow * AS + (wave * kq + (lane >> 5) * 8) * 2;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (u < ksteps) {
+        for (int t = 0; t < TG; ++t) {
+            const int tap = g * TG + t;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int ny = py + dy, nx = px + dx;
+            const int nrow = (ny >= 0 && ny < W && nx >= 0 && nx < W) ? r + dy * W + dx : 32;
+            const char* ap = s_a + nrow * AS + (wave * kq + (lane >> 5) * 8) * 2;
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
                 const bf16x8 av = *(const bf16x8*)(ap + u * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bcur[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[g & 1][t][u], acc, 0, 0, 0);
             }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bcur[u] = bnext[u];
+        }
     }
     // ---- add the four partial tiles
 #pragma unroll
@@ -231,14 +236,16 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     const size_t lds = (size_t)33 * (Cin * 2 + 16) + 4 * 32 * 33 * 4;      // the statistics table of the fused GroupNorm fits the partial-tile area
     const long long rows = (long long)d->N * d->IH * d->IW;
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)(d->CoutW / 32));
-    if (d->IW == 2) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ddpm_check_launch("conv_small: raise dynamic LDS limit") ? -1 : -1;
-        hipLaunchKernelGGL(conv_small_kernel<2>, grid, dim3(256), lds, stream, a);
-    } else {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ddpm_check_launch("conv_small: raise dynamic LDS limit") ? -1 : -1;
-        hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), lds, stream, a);
+    const int ks = Cin / 64;
+    if (ks != 1 && ks != 2 && ks != 4 && ks != 8) return 0;
+#define SMALL_CASE(Wv, KSv)                                                                                                      \
+    if (d->IW == Wv && ks == KSv) {                                                                                              \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_small_kernel<Wv, KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   (int)lds) != hipSuccess)                                                      \
+            return ddpm_check_launch("conv_small: raise dynamic LDS limit") ? -1 : -1;                                           \
+        hipLaunchKernelGGL((conv_small_kernel<Wv, KSv>), grid, dim3(256), lds, stream, a);                                        \
     }
+    SMALL_CASE(2, 1) SMALL_CASE(2, 2) SMALL_CASE(2, 4) SMALL_CASE(2, 8) SMALL_CASE(4, 1) SMALL_CASE(4, 2) SMALL_CASE(4, 4) SMALL_CASE(4, 8)
+#undef SMALL_CASE
     return ddpm_check_launch("conv_small") == DDPM_OK ? 1 : -1;
 }
