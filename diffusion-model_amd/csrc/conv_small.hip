@@ -1,4 +1,4 @@
-// 3x3 stride-1 convolution (forward or data-gradient form) on images of 2x2 or 4x4 pixels.
+// 3x3 stride-1 convolution (forward or data-gradient form) on images of 2x2, 4x4 or 8x8 pixels.
 //
 // The deepest UNet stages run 3x3 convolutions with 128-512 channels on a few pixels per image: a GEMM with only
 // N*H*W = 1-4 K rows but K = 9*Cin up to 4608 deep.  The general tap-list kernel walks K in 32-channel chunks with a
@@ -31,24 +31,25 @@ struct SmallConvArgs {
 template <int W, int KS>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) {
     constexpr int HW = W * W;
+    constexpr int MB = HW > 32 ? HW / 32 : 1, ROWS = 32 * MB;     // 32-row MFMA blocks per tile: an 8x8 image is two
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Cin = a.C0 + a.C1;
     const int AS = Cin * 2 + 16;
-    char* s_a = smem;                                  // [33][AS]; row 32 stays zero
-    float* s_red = (float*)(smem + 33 * AS);           // [4][32][33]
+    char* s_a = smem;                                  // [ROWS + 1][AS]; the last row stays zero
+    float* s_red = (float*)(smem + (ROWS + 1) * AS);   // [4][ROWS][33]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row0 = (long long)blockIdx.x * 32;
+    const long long row0 = (long long)blockIdx.x * ROWS;
     const long long rows_total = (long long)a.N * HW;
     const int co0 = blockIdx.y * 32;
 
     // ---- input rows of this tile's images -> LDS (concat of two sources; broadcast add on source 0)
     const int vpr = Cin / 8;
-    for (int idx = tid; idx < 33 * vpr; idx += 256) {
+    for (int idx = tid; idx < (ROWS + 1) * vpr; idx += 256) {
         const int row = idx / vpr, c = (idx - row * vpr) * 8;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
-        if (row < 32 && row0 + row < rows_total) {
+        if (row < ROWS && row0 + row < rows_total) {
             if (c < a.C0) {
                 v = *(const bf16x8*)(a.in0 + (row0 + row) * a.C0 + c);
                 if (a.in_add) {
@@ -67,12 +68,13 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
     constexpr int kq = 16 * KS;                        // channels per wave
     constexpr int TG = KS <= 4 ? 9 : 3, NG = 9 / TG;   // taps per group, groups
     const int r = lane & 31;
-    const int p = r % HW, py = p / W, px = p % W;
     const bf16* wbase = a.w + ((long long)(co0 + r) * Cin + wave * kq + (lane >> 5) * 8);
     const long long slice = (long long)a.w_rows * Cin;
-    f32x16 acc;
+    f32x16 acc[MB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
     bf16x8 bw[NG > 1 ? 2 : 1][TG][KS];
 #pragma unroll
     for (int t = 0; t < TG; ++t)
@@ -91,53 +93,65 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
         for (int t = 0; t < TG; ++t) {
             const int tap = g * TG + t;
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int ny = py + dy, nx = px + dx;
-            const int nrow = (ny >= 0 && ny < W && nx >= 0 && nx < W) ? r + dy * W + dx : 32;
-            const char* ap = s_a + nrow * AS + (wave * kq + (lane >> 5) * 8) * 2;
 #pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                const bf16x8 av = *(const bf16x8*)(ap + u * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[g & 1][t][u], acc, 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb) {
+                const int rr = mb * 32 + r;
+                const int p = rr % HW, py = p / W, px = p % W;
+                const int ny = py + dy, nx = px + dx;
+                const int nrow = (ny >= 0 && ny < W && nx >= 0 && nx < W) ? rr + dy * W + dx : ROWS;
+                const char* ap = s_a + nrow * AS + (wave * kq + (lane >> 5) * 8) * 2;
+#pragma unroll
+                for (int u = 0; u < KS; ++u) {
+                    const bf16x8 av = *(const bf16x8*)(ap + u * 32);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[g & 1][t][u], acc[mb], 0, 0, 0);
+                }
             }
         }
     }
     // ---- add the four partial tiles
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        s_red[(wave * 32 + row) * 33 + (lane & 31)] = acc[i];
-    }
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            s_red[(wave * ROWS + row) * 33 + (lane & 31)] = acc[mb][i];
+        }
     __syncthreads();
-    const int row = tid >> 3, c4 = (tid & 7) * 4;
-    const long long grow = row0 + row;
-    const bool live = grow < rows_total;
-    const long long e = grow * a.out_cs + co0 + c4;
-    float val[4];
+    const int c4 = (tid & 7) * 4;
+    float val[MB][4];
+    bool live[MB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int co = co0 + c4 + j;
-        const float v = s_red[(0 * 32 + row) * 33 + c4 + j] + s_red[(1 * 32 + row) * 33 + c4 + j] +
-                        s_red[(2 * 32 + row) * 33 + c4 + j] + s_red[(3 * 32 + row) * 33 + c4 + j];
-        val[j] = act_fwd(v + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
-    }
-    if (live) {
-        bf16x4 o;
+    for (int mb = 0; mb < MB; ++mb) {
+        const int row = mb * 32 + (tid >> 3);
+        const long long grow = row0 + row;
+        live[mb] = grow < rows_total;
+        const long long e = grow * a.out_cs + co0 + c4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)val[j];
-        if (a.sum_out) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (co0 + c4 + j < a.Cout) atomicAdd(a.sum_out + (grow / HW) * a.Cout + co0 + c4 + j, val[j]);
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + c4 + j;
+            const float v = s_red[(0 * ROWS + row) * 33 + c4 + j] + s_red[(1 * ROWS + row) * 33 + c4 + j] +
+                            s_red[(2 * ROWS + row) * 33 + c4 + j] + s_red[(3 * ROWS + row) * 33 + c4 + j];
+            val[mb][j] = act_fwd(v + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
         }
-        if (a.res) {
-            const bf16x4 rv = *(const bf16x4*)(a.res + e);
+        if (live[mb]) {
+            bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] + (float)rv[j]);
-        }
-        if (co0 + c4 + 4 <= a.Cout) {
-            *(bf16x4*)(a.out + e) = o;
-        } else {
-            for (int j = 0; j < a.Cout - co0 - c4; ++j) a.out[e + j] = o[j];
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)val[mb][j];
+            if (a.sum_out) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (co0 + c4 + j < a.Cout) atomicAdd(a.sum_out + (grow / HW) * a.Cout + co0 + c4 + j, val[mb][j]);
+            }
+            if (a.res) {
+                const bf16x4 rv = *(const bf16x4*)(a.res + e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] + (float)rv[j]);
+            }
+            if (co0 + c4 + 4 <= a.Cout) {
+                *(bf16x4*)(a.out + e) = o;
+            } else {
+                for (int j = 0; j < a.Cout - co0 - c4; ++j) a.out[e + j] = o[j];
+            }
         }
     }
     if (!a.gn_gamma) return;
@@ -145,24 +159,29 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
     // ---- fused GroupNorm + activation: statistics over the bf16-rounded raw values, as the separate kernel would read them
     const int cpg = a.Cout / a.gn_groups;              // 32 % cpg == 0, Cout % 32 == 0, no conv activation / residual (host-checked)
     const int gpt = 32 / cpg;                          // groups in this tile
-    f32x4 gam = *(const f32x4*)(a.gn_gamma + co0 + c4), bet = *(const f32x4*)(a.gn_beta + co0 + c4);
-    bf16x4 rv4;
+    const f32x4 gam = *(const f32x4*)(a.gn_gamma + co0 + c4), bet = *(const f32x4*)(a.gn_beta + co0 + c4);
+    bf16x4 rv4[MB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rv4[j] = (bf16)0.f;
-    if (a.gn_res && live) rv4 = *(const bf16x4*)(a.gn_res + e);
-    __syncthreads();                                   // partial tiles consumed: reuse the table as [32][33] values + [32 pairs][2] statistics
-    float* s_val = s_red;
-    float* s_st = s_red + 32 * 33;
+    for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        val[j] = (float)(bf16)val[j];
-        s_val[row * 33 + c4 + j] = live ? val[j] : 0.f;
+        for (int j = 0; j < 4; ++j) rv4[mb][j] = (bf16)0.f;
+        if (a.gn_res && live[mb]) rv4[mb] = *(const bf16x4*)(a.gn_res + (row0 + mb * 32 + (tid >> 3)) * a.out_cs + co0 + c4);
     }
+    __syncthreads();                                   // partial tiles consumed: reuse the table as [ROWS][33] values + [pairs][2] statistics
+    float* s_val = s_red;
+    float* s_st = s_red + ROWS * 33;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            val[mb][j] = (float)(bf16)val[mb][j];
+            s_val[(mb * 32 + (tid >> 3)) * 33 + c4 + j] = live[mb] ? val[mb][j] : 0.f;
+        }
     __syncthreads();
     {
         // pair = (image of the tile, group of the tile); eight threads per pair, HW * cpg / 8 values each
         const int pair = tid >> 3, sub = tid & 7;
-        const int npairs = (32 / HW) * gpt;
+        const int npairs = (ROWS / HW) * gpt;
         float s1 = 0.f, s2 = 0.f;
         if (pair < npairs) {
             const int img = pair / gpt, grp = pair - img * gpt;
@@ -190,27 +209,31 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
         }
     }
     __syncthreads();
-    if (live) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        if (!live[mb]) continue;
+        const int row = mb * 32 + (tid >> 3);
         const int pair = (row / HW) * gpt + c4 / cpg;  // cpg >= 4: the four channels of a thread share a group
         const float mean = s_st[pair * 2], rstd = s_st[pair * 2 + 1];
         bf16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float sc = gam[j] * rstd, sh = bet[j] - mean * sc;
-            float y = act_fwd(val[j] * sc + sh, a.gn_act);
-            if (a.gn_res) y += (float)rv4[j];
+            float y = act_fwd(val[mb][j] * sc + sh, a.gn_act);
+            if (a.gn_res) y += (float)rv4[mb][j];
             o[j] = (bf16)y;
         }
-        *(bf16x4*)(a.gn_out + grow * a.Cout + co0 + c4) = o;
+        *(bf16x4*)(a.gn_out + (row0 + row) * a.Cout + co0 + c4) = o;
     }
 }
 
 // Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
 extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
-    if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4)) return 0;
+    if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
     if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->res || d->act != 0 || d->sum_out) return 0;
     const int Cin = d->C0 + d->C1;
     if (Cin % 64 || Cin > 512 || d->C0 % 8 || d->C1 % 8 || d->out_cs != d->Cout) return 0;
+    if (d->IW == 8 && Cin > 256) return 0;
     if (d->gn_groups <= 0 || d->Cout % 32 || d->Cout % d->gn_groups) return 0;
     const int cpg = d->Cout / d->gn_groups;
     return cpg >= 4 && cpg <= 32 && 32 % cpg == 0;
@@ -218,11 +241,12 @@ extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
 
 // Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
 int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
-    if (d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4)) return 0;
+    if (d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
     if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask) return 0;
     if (d->out2) return 0;
     const int Cin = d->C0 + d->C1;
     if (Cin % 64 || Cin > 512 || d->C0 % 8 || d->C1 % 8 || d->out_cs % 4) return 0;
+    if (d->IW == 8 && Cin > 256) return 0;             // 8x8 images: the UNet's 64-wide stage (two sources when concatenated)
     SmallConvArgs a;
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1; a.in_add = d->in_add;
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out; a.res = (const bf16*)d->res; a.sum_out = d->sum_out;
@@ -233,9 +257,10 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
         ddpm_set_error("conv: the fused GroupNorm needs gamma, beta, an output and a shape ddpm_conv_gn_fusable() accepts");
         return -1;
     }
-    const size_t lds = (size_t)33 * (Cin * 2 + 16) + 4 * 32 * 33 * 4;      // the statistics table of the fused GroupNorm fits the partial-tile area
+    const int tile_rows = d->IW == 8 ? 64 : 32;        // whole images: 8 of 2x2, 2 of 4x4, 1 of 8x8
+    const size_t lds = (size_t)(tile_rows + 1) * (Cin * 2 + 16) + (size_t)4 * tile_rows * 33 * 4;      // the statistics table of the fused GroupNorm fits the partial-tile area
     const long long rows = (long long)d->N * d->IH * d->IW;
-    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)(d->CoutW / 32));
+    dim3 grid((unsigned)((rows + tile_rows - 1) / tile_rows), (unsigned)(d->CoutW / 32));
     const int ks = Cin / 64;
     if (ks != 1 && ks != 2 && ks != 4 && ks != 8) return 0;
 #define SMALL_CASE(Wv, KSv)                                                                                                      \
@@ -246,6 +271,7 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
         hipLaunchKernelGGL((conv_small_kernel<Wv, KSv>), grid, dim3(256), lds, stream, a);                                        \
     }
     SMALL_CASE(2, 1) SMALL_CASE(2, 2) SMALL_CASE(2, 4) SMALL_CASE(2, 8) SMALL_CASE(4, 1) SMALL_CASE(4, 2) SMALL_CASE(4, 4) SMALL_CASE(4, 8)
+    SMALL_CASE(8, 1) SMALL_CASE(8, 2) SMALL_CASE(8, 4)
 #undef SMALL_CASE
     return ddpm_check_launch("conv_small") == DDPM_OK ? 1 : -1;
 }

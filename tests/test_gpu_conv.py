@@ -36,6 +36,7 @@ CASES = [
     # kind, N, Cin, Cout, H, W
     (hip.CONV_3X3_S1, 2, 32, 32, 16, 16),
     (hip.CONV_3X3_S1, 3, 64, 32, 8, 8),
+    (hip.CONV_3X3_S1, 5, 128, 64, 8, 8),
     (hip.CONV_3X3_S1, 5, 256, 512, 2, 2),
     (hip.CONV_3X3_S1, 2, 16, 32, 32, 32),     # stem-like (3 real channels padded to 16)
     (hip.CONV_3X3_S1, 2, 32, 3, 32, 32),      # image head
@@ -128,6 +129,9 @@ def test_conv_rejects_bad_shapes(dev):
     (5, 128, 0, 128, 4, 16, "silu", True, False),
     (4, 256, 256, 256, 2, 16, "gelu", False, True),    # decoder: concatenated skip connection
     (3, 256, 0, 512, 2, 32, "relu", False, False),
+    (5, 64, 0, 64, 8, 16, "gelu", False, True),        # 8x8: one image per 64-row tile
+    (3, 64, 64, 64, 8, 16, "silu", True, False),
+    (2, 128, 0, 128, 8, 16, "gelu", False, False),
 ])
 def test_conv_with_fused_groupnorm(dev, n, ci, c1, co, hw, groups, act, with_res, with_add):
     """conv -> GroupNorm -> act (+ residual) finished inside the convolution's launch (2x2 / 4x4 images): raw result,
@@ -165,7 +169,7 @@ def test_conv_with_fused_groupnorm(dev, n, ci, c1, co, hw, groups, act, with_res
     assert torch.equal(raw, raw2)
     torch.testing.assert_close(stats, stats2, rtol=1e-4, atol=1e-5)
     assert_rel(y.float().cpu(), y2.float().cpu(), 1e-2)
-    assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, nhwc(r16(hash_normal((2, 64, 8, 8), 69)), dev), None, 64, 16)
+    assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, nhwc(r16(hash_normal((2, 32, 16, 16), 69)), dev), None, 32, 16)   # image larger than a tile
 
 
 @pytest.mark.parametrize("n,c_used,co,h,wd,act", [(3, 1, 32, 32, 32, "gelu"), (2, 3, 32, 20, 72, "none"), (1, 3, 32, 64, 64, "silu"), (2, 4, 24, 8, 8, "none")])
