@@ -24,6 +24,11 @@ struct SmallConvArgs {
     // optional fused GroupNorm + activation (+ residual) of the result: a tile holds whole images and whole groups
     const float* gn_gamma; const float* gn_beta; bf16* gn_out; float* gn_stats; const bf16* gn_res;
     int gn_groups, gn_act; float gn_eps;
+    // optional GroupNorm + activation BACKWARD applied to the input on its way into LDS (data-gradient launches): in0 is then
+    // the gradient of the normalised, activated tensor; the tile holds whole images and all channels, so the statistics of
+    // the backward pass are complete inside the workgroup
+    const bf16* gnb_raw; const float* gnb_gamma; const float* gnb_beta; const float* gnb_stats; float* gnb_part; bf16* gnb_draw;
+    int gnb_groups, gnb_act;
 };
 
 // KS = MFMA k-steps per wave and tap (Cin = 64 * KS).  The weight fragments of a whole group of taps are requested at once
@@ -44,6 +49,106 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
 
     // ---- input rows of this tile's images -> LDS (concat of two sources; broadcast add on source 0)
     const int vpr = Cin / 8;
+    if (a.gnb_raw) {
+        // GroupNorm + activation backward on the way in.  unit = (image of the tile, 8-channel vector), tpu threads per
+        // unit share its HW rows; with g = dy act'(z), xh = (x - mean) rstd:  dgamma = sum g xh, dbeta = sum g,
+        // dx = rstd (gamma g - (S1 + xh S2) / m),  S1 = sum_group gamma g, S2 = sum_group gamma g xh,  m = cpg HW.
+        constexpr int IPT = ROWS / HW;
+        const int C = Cin, G = a.gnb_groups, cpg = C / G;
+        const int units = IPT * vpr, tpu = 256 / units, rpt = HW / tpu;     // host-checked: 4 <= units <= 256, rpt in {1, 2, 4}
+        const int unit = tid / tpu, sub = tid - unit * tpu;
+        const int img = unit / vpr, vec = unit - img * vpr;
+        const long long n = row0 / HW + img;
+        const bool have = n < a.N;
+        float ga[8], be[8], mean[8], rstd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = vec * 8 + j, grp = c / cpg;
+            ga[j] = a.gnb_gamma[c]; be[j] = a.gnb_beta[c];
+            mean[j] = have ? a.gnb_stats[(n * G + grp) * 2] : 0.f;
+            rstd[j] = have ? a.gnb_stats[(n * G + grp) * 2 + 1] : 0.f;
+        }
+        float gv[4][8], xh[4][8];
+        float a1[8], a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < rpt) {
+                const long long e = (row0 + img * HW + sub * rpt + k) * C + vec * 8;
+                bf16x8 xv, dv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xv[j] = (bf16)0.f; dv[j] = (bf16)0.f; }
+                if (have) { xv = *(const bf16x8*)(a.gnb_raw + e); dv = *(const bf16x8*)(a.in0 + e); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[k][j] = ((float)xv[j] - mean[j]) * rstd[j];
+                    gv[k][j] = (float)dv[j] * act_bwd(xh[k][j] * ga[j] + be[j], a.gnb_act);
+                    a1[j] += gv[k][j]; a2[j] += gv[k][j] * xh[k][j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            for (int o = 1; o < tpu; o <<= 1) { a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); }
+        if (have && sub == 0 && blockIdx.y == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a.gnb_part[(n * 3 + 0) * C + vec * 8 + j] = a2[j];
+                a.gnb_part[(n * 3 + 1) * C + vec * 8 + j] = a1[j];
+            }
+        }
+        float S1[8], S2[8];
+        const float im = 1.0f / (float)(cpg * HW);
+        if (cpg >= 8) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { u += a1[j] * ga[j]; v += a2[j] * ga[j]; }
+            for (int o = tpu; o < tpu * (cpg / 8); o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { S1[j] = u * im; S2[j] = v * im; }
+        } else {                                       // cpg == 4: two groups inside the vector
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float u = 0.f, v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { u += a1[h * 4 + j] * ga[h * 4 + j]; v += a2[h * 4 + j] * ga[h * 4 + j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { S1[h * 4 + j] = u * im; S2[h * 4 + j] = v * im; }
+            }
+        }
+        float db[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) db[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < rpt) {
+                const int row = img * HW + sub * rpt + k;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dd = rstd[j] * (ga[j] * gv[k][j] - (S1[j] + xh[k][j] * S2[j]));
+                    db[j] += dd;
+                    o[j] = (bf16)dd;
+                }
+                *(bf16x8*)(s_a + row * AS + vec * 16) = o;
+                if (have && blockIdx.y == 0) *(bf16x8*)(a.gnb_draw + (row0 + row) * C + vec * 8) = o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            for (int o = 1; o < tpu; o <<= 1) db[j] += __shfl_xor(db[j], o, 64);
+        if (have && sub == 0 && blockIdx.y == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a.gnb_part[(n * 3 + 2) * C + vec * 8 + j] = db[j];
+        }
+        for (int idx = tid; idx < vpr; idx += 256) {   // the zero row
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+            *(bf16x8*)(s_a + ROWS * AS + idx * 16) = z;
+        }
+    } else
     for (int idx = tid; idx < (ROWS + 1) * vpr; idx += 256) {
         const int row = idx / vpr, c = (idx - row * vpr) * 8;
         bf16x8 v;
@@ -227,6 +332,21 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
     }
 }
 
+// Whether the GroupNorm backward described by the gnb_* fields can run in the loader of this (data-gradient) launch.
+extern "C" int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d) {
+    if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
+    if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->in_add || d->C1 != 0 || d->out2 || d->gn_gamma) return 0;
+    const int C = d->C0, hw = d->IH * d->IW;
+    if (C % 64 || C > 512 || (d->IW == 8 && C > 256) || d->out_cs % 4 || d->gnb_groups <= 0 || C % d->gnb_groups) return 0;
+    const int cpg = C / d->gnb_groups, rows = hw > 32 ? hw : 32;
+    const int units = (rows / hw) * (C / 8);
+    if (units < 4 || units > 256 || (256 % units)) return 0;
+    const int tpu = 256 / units;
+    if (tpu > hw || hw % tpu || hw / tpu > 4) return 0;
+    if (cpg == 4) return 1;
+    return cpg % 8 == 0 && ((cpg / 8) & (cpg / 8 - 1)) == 0 && tpu * (cpg / 8) <= 64;
+}
+
 // Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
 extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
     if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
@@ -253,6 +373,12 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     a.N = d->N; a.Cout = d->Cout; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act;
     a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_out = (bf16*)d->gn_out; a.gn_stats = d->gn_stats; a.gn_res = (const bf16*)d->gn_res;
     a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps;
+    a.gnb_raw = (const bf16*)d->gnb_raw; a.gnb_gamma = d->gnb_gamma; a.gnb_beta = d->gnb_beta; a.gnb_stats = d->gnb_stats;
+    a.gnb_part = d->gnb_part; a.gnb_draw = (bf16*)d->gnb_draw; a.gnb_groups = d->gnb_groups; a.gnb_act = d->gnb_act;
+    if (d->gnb_raw && !(d->gnb_gamma && d->gnb_beta && d->gnb_stats && d->gnb_part && d->gnb_draw && ddpm_conv_gnb_fusable(d))) {
+        ddpm_set_error("conv: the fused GroupNorm backward needs all gnb_* pointers and a shape ddpm_conv_gnb_fusable() accepts");
+        return -1;
+    }
     if (d->gn_gamma && !(d->gn_beta && d->gn_out && ddpm_conv_gn_fusable(d))) {
         ddpm_set_error("conv: the fused GroupNorm needs gamma, beta, an output and a shape ddpm_conv_gn_fusable() accepts");
         return -1;

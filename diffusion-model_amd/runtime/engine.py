@@ -390,6 +390,27 @@ class UNetEngine:
                 if res is not None:                       # residual input receives the same gradient (no copy)
                     assert res.g is None
                     res.g = dy
+                wd = wc.dgrad[name]
+                c0 = x0.v.shape[3]
+                dk = pack.DGRAD_KIND[kind]
+                if (norm and out_mask is None and x0.need_grad and dk == K33
+                        and ops.conv_gnb_fusable(dk, dy, c0, groups, masked=in_mask is not None)):
+                    # low-resolution stages: the GroupNorm / activation backward runs in the loader of the data-gradient
+                    # convolution (its tile holds whole images and all channels), which also writes the raw gradient the
+                    # weight-gradient launch reads later
+                    draw = torch.empty_like(raw)
+                    dsum = self._take_zeros(n * c0, dev).view(n, c0) if in_add is not None else None
+                    x0.g = ops.conv_forward(dk, dy, wd, None, c0, res=x0.g, rows=c0, sum_out=dsum,
+                                            gnb=(raw, gamma, beta, groups, act, stats, gn_partials(cout, norm, name), draw))
+                    out.g = None
+                    wgrad(kind, x0.v, draw, cout, name, x1=None if x1 is None else x1.v,
+                          in_add=None if in_add is None else in_add.v, in_mask=in_mask)
+                    if in_add is not None:
+                        in_add.g = dsum
+                    if x1 is not None:
+                        c1 = x1.v.shape[3]
+                        x1.g = ops.conv_forward(dk, draw, wd, None, c1, res=x1.g, row0=c0, rows=c1)
+                    return
                 splits = ops.act_backward_splits(raw) if (norm is None and out_mask is None) else 0
                 if splits:
                     # bare activation: a streaming kernel with many workgroups per image; its partial bias-gradient rows
@@ -405,9 +426,6 @@ class UNetEngine:
                       in_add=None if in_add is None else in_add.v, in_mask=in_mask)
                 if not x0.need_grad:
                     return                                  # network inputs (image, sinusoid) need no gradient
-                wd = wc.dgrad[name]
-                c0 = x0.v.shape[3]
-                dk = pack.DGRAD_KIND[kind]
                 # gradient of the broadcast add = per-image spatial sum of this conv's own data-gradient,
                 # accumulated in fp32 inside the kernel (x0.g, added afterwards, belongs to other consumers)
                 dsum = self._take_zeros(n * c0, dev).view(n, c0) if in_add is not None else None

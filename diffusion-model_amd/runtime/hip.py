@@ -30,7 +30,9 @@ class ConvDesc(C.Structure):
         ("Cout", _i), ("CoutW", _i), ("out_cs", _i), ("w_rows", _i),
         ("act", _i), ("out_mode", _i), ("sum_out", _vp),
         ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_stats", _vp), ("gn_res", _vp),
-        ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("out2", _vp), ("act2", _i), ("C0_used", _i),
+        ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("out2", _vp), ("act2", _i),
+        ("gnb_raw", _vp), ("gnb_gamma", _vp), ("gnb_beta", _vp), ("gnb_stats", _vp), ("gnb_part", _vp), ("gnb_draw", _vp),
+        ("gnb_groups", _i), ("gnb_act", _i), ("C0_used", _i),
     ]
 
 
@@ -115,6 +117,7 @@ _PROTOS = {
     "ddpm_prepare_images": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
     "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),
+    "ddpm_conv_gnb_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_scratch_floats": ([C.POINTER(GnDesc), _i], _i64),

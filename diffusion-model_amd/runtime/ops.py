@@ -49,10 +49,12 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                  in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0, act: int = 0,
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
                  out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
-                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None):
+                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None, gnb=None):
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
     (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
     sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res.
+    gnb = (raw, gamma, beta, groups, act, stats, part, draw): x0 is the gradient of a conv -> GroupNorm -> act unit's output;
+    the GroupNorm/activation backward runs in the loader (where conv_gnb_fusable says so), filling part [N][3][C] and draw.
     act2: also return act2(result) as a second tensor (the result itself without activation): returns (raw, y).
     c0_used: promise that only the first c0_used (1..4) channels of x0 are non-zero (zero-padded image tensors).
     gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
@@ -74,6 +76,10 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out), C0_used=c0_used)
     y = stats = None
+    if gnb is not None:
+        g_raw, g_gamma, g_beta, g_groups, g_act, g_stats, g_part, g_draw = gnb
+        d.gnb_raw, d.gnb_gamma, d.gnb_beta, d.gnb_stats = hip.ptr(g_raw), hip.ptr(g_gamma), hip.ptr(g_beta), hip.ptr(g_stats)
+        d.gnb_part, d.gnb_draw, d.gnb_groups, d.gnb_act = hip.ptr(g_part), hip.ptr(g_draw), g_groups, g_act
     if act2 is not None:
         y = torch.empty_like(out)
         d.out2, d.act2 = hip.ptr(y), act2
@@ -88,13 +94,24 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
         # every operand once: activations in, weight rows used, bias, epilogue operands, result
         wbytes = _SLICES[kind] * d.CoutW * (c0 + c1) * 2
         obytes = n * oh * ow * cout * (4 if f32_nchw else 2)
-        return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out, y, stats, None if gn is None else gn[4]) + wbytes + cout * 4 + obytes,
+        extra = 0 if gnb is None else _nb(gnb[0], gnb[5], gnb[6], gnb[7])
+        return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out, y, stats, None if gn is None else gn[4]) + wbytes + cout * 4 + obytes + extra,
                 2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}")
 
     _launch("conv_mfma_kernel", cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
     if act2 is not None:
         return out, y
     return out if gn is None else (out, y, stats)
+
+
+def conv_gnb_fusable(kind: int, dy: Tensor, cout: int, groups: int, masked: bool = False) -> bool:
+    """Whether conv_forward(kind, dy, ..., gnb=...) is available: kind = the data-gradient kind, dy = gradient of the unit's
+    output ([N,H,W,C]), cout = channels of the data-gradient, groups = the unit's GroupNorm groups."""
+    n, ih, iw, c0 = dy.shape
+    d = hip.ConvDesc(kind=kind, N=n, IH=ih, IW=iw, C0=c0, C1=0, Cout=cout, out_cs=cout, CoutW=(cout + 31) // 32 * 32,
+                     w_rows=(cout + 31) // 32 * 32, out_mode=hip.OUT_BF16_NHWC, gnb_groups=groups,
+                     out_mask=(1 if masked else None))
+    return bool(hip.lib().ddpm_conv_gnb_fusable(C.byref(d)))
 
 
 def conv_gn_fusable(kind: int, x0: Tensor, x1: Optional[Tensor], cout: int, groups: int) -> bool:

@@ -129,11 +129,19 @@ typedef struct ddpm_conv_desc {
     float gn_eps;
     void* out2; int act2;      /* optional second NHWC bf16 result act2(out) (out itself without activation): a conv -> act unit keeps
                                 * the pre-activation for its backward pass and hands the activated tensor on, in one launch */
+    /* Optional GroupNorm + activation BACKWARD applied to in0 on its way in (the data-gradient launch of a conv -> GroupNorm ->
+     * act unit's own convolution): in0 = gradient of the unit's output, gnb_raw = the unit's raw
+     * convolution result, gnb_stats [N][G][2] its statistics; the launch also writes gnb_draw (gradient of the raw result, which
+     * the weight-gradient reads) and gnb_part [N][3][C] (per-image dgamma, dbeta, bias-gradient rows).  Only where
+     * ddpm_conv_gnb_fusable() returns 1 (2x2 / 4x4 / 8x8 images: a tile holds whole images and all channels). */
+    const void* gnb_raw; const float* gnb_gamma; const float* gnb_beta; const float* gnb_stats; float* gnb_part; void* gnb_draw;
+    int gnb_groups, gnb_act;
     int C0_used;               /* 0, or a promise that only the first C0_used (1..4) channels of in0 are non-zero (an image stored
                                 * zero-padded to 16 channels: the stem, and the head's data-gradient): lets a 3x3 convolution to 32
                                 * channels run on a kernel that reads only those. */
 } ddpm_conv_desc;
 int ddpm_conv_gn_fusable(const ddpm_conv_desc* d);
+int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d);
 
 /* y = act(conv(x) + bias) [* mask] [+ res] for every kind above. */
 int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream);

@@ -206,3 +206,35 @@ def test_conv_second_activated_result(dev):
         assert torch.equal(raw, raw0)
         assert_rel(nchw(raw), F.conv2d(x, w, b, padding=1))
         assert_rel(y.float().cpu(), O.act_fn("gelu")(raw.float().cpu()), 1e-2)
+
+
+@pytest.mark.parametrize("n,c,c0,hw,groups,act", [(9, 256, 256, 2, 16, "gelu"), (5, 128, 128, 4, 16, "silu"), (3, 64, 64, 8, 16, "gelu"),
+                                                    (2, 256, 128, 4, 16, "gelu"), (4, 128, 64, 8, 16, "relu")])
+def test_conv_dgrad_with_fused_groupnorm_backward(dev, n, c, c0, hw, groups, act):
+    """Data-gradient convolution whose loader applies the GroupNorm + activation backward (2x2 / 4x4 / 8x8 images): the raw
+    gradient, the per-image parameter-gradient rows and the data-gradient must match the two-launch path (same kernels'
+    arithmetic, different reduction order): 1e-2 of the scale for bf16 tensors, 2e-3 relative for the fp32 rows."""
+    raw = r16(hash_normal((n, hw, hw, c), 101) * 1.3 + 0.1).to(dev).bfloat16()
+    dy = r16(hash_normal((n, hw, hw, c), 102)).to(dev).bfloat16()
+    gamma, beta = (1 + 0.3 * hash_normal((c,), 103)).to(dev), (0.3 * hash_normal((c,), 104)).to(dev)
+    w = r16(hash_normal((c, c0, 3, 3), 105) * (1.0 / (3 * c ** 0.5)))
+    wd = pack.pack_dgrad(hip.CONV_3X3_S1, w).to(dev)
+    res = r16(hash_normal((n, hw, hw, c0), 106)).to(dev).bfloat16()
+    _, stats = ops.gn_act_forward(raw, gamma, beta, groups, hip.ACT[act])
+    # two launches
+    part0 = torch.zeros(n, 3, c, device=dev)
+    draw0 = ops.gn_act_backward(raw, dy, gamma, beta, groups, hip.ACT[act], stats, part0)
+    dsum0 = torch.zeros(n, c0, device=dev)
+    dx0 = ops.conv_forward(hip.CONV_3X3_S1, draw0, wd, None, c0, res=res, rows=c0, sum_out=dsum0)
+    # one launch
+    assert ops.conv_gnb_fusable(hip.CONV_3X3_S1, dy, c0, groups)
+    part1 = torch.full((n, 3, c), float("nan"), device=dev)
+    draw1 = torch.full_like(raw, float("nan"))
+    dsum1 = torch.zeros(n, c0, device=dev)
+    dx1 = ops.conv_forward(hip.CONV_3X3_S1, dy, wd, None, c0, res=res, rows=c0, sum_out=dsum1,
+                           gnb=(raw, gamma, beta, groups, hip.ACT[act], stats, part1, draw1))
+    assert_rel(draw1.float().cpu(), draw0.float().cpu())
+    assert_rel(dx1.float().cpu(), dx0.float().cpu())
+    torch.testing.assert_close(part1.cpu(), part0.cpu(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(dsum1.cpu(), dsum0.cpu(), rtol=1e-2, atol=2e-2)
+    assert not ops.conv_gnb_fusable(hip.CONV_3X3_S1, torch.empty(2, 16, 16, 32, device=dev, dtype=torch.bfloat16), 32, 16)
