@@ -130,7 +130,9 @@ class PipelinedTrainStep:
         self.criterion, self.optimizer, self.reducer, self.x0 = criterion, optimizer, reducer, x0
         self.unet = self.core.model
         self.eng = self.unet._get_engine()
-        self.eng.always_repack = True
+        # the kernel-layout weight copies are refreshed right after the optimizer step (see _adam), not at the head of the
+        # next forward pass: there the launch falls into the start-up latency of the next step's first graph
+        self.eng.always_repack = False
         self.eng.mask_ahead = True
         if int(phases) < 2:
             raise ValueError("phases must be 2, 4 or larger (= one phase per stage)")
@@ -228,6 +230,8 @@ class PipelinedTrainStep:
     def _adam(self):
         self.optimizer.step()
         self.eng.commit_masks()
+        params = dict(zip(self.unet._param_names, self.unet.parameters()))
+        self.eng.wc.refresh(params, self.x0.device, force=True)
 
     @torch.no_grad()
     def _pre(self):
