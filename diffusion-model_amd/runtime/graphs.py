@@ -107,11 +107,13 @@ class PipelinedTrainStep:
     work) on a side stream, W_p beside M_{p+1}:
 
         main:  [A: t, q, forward, ELBO, M_0] [M_1] [M_2] [M_3] ........ wait side ( -> [C: Adam] when data parallel)
-        side:  [next step's dropout bits]     [W_0]  [W_1]  [W_2]  [W_3 + gradients to torch layout + Adam]
+        side:                                 [W_0]  [W_1]  [W_2]  [W_3 + gradients to torch layout + Adam + weight
+                                                                    re-layout] [next step's dropout bits]
 
     Single GPU: the optimizer step closes the last leaf graph (every graph start costs tens of microseconds on the device,
-    so the critical path holds as few as possible), and the next step's dropout keep bits are drawn by two plain launches
-    at the head of the side stream, beside the forward pass (double-buffered in the engine: mask_ahead).
+    so the critical path holds as few as possible), followed by the weight re-layout; the next step's dropout keep bits
+    (double-buffered in the engine: mask_ahead) are two plain launches behind it that the main stream does not wait for:
+    they run inside the start-up latency of the next step's first graph.
 
     (4 phases measured best: with one phase per stage the leaf launches become too small to keep the side stream ahead.
     The last phase's leaf work runs alone, so its weight-gradient problems are cut into more, shorter position splits.)
@@ -255,15 +257,16 @@ class PipelinedTrainStep:
     def _run(self, graphs, exchange: bool = True):
         main = torch.cuda.current_stream()
         gm, gw, gc, gp = graphs if graphs is not None else (None, None, None, None)
-        if graphs is None:
-            self._pre()
-        elif gp:
-            # two plain launches with persistent arguments, not a graph: a graph launch costs tens of microseconds of
-            # start-up on the device and would delay the start of the forward graph behind it
-            if self.reducer is not None:
-                self.side.wait_event(self.ev_done)      # the previous step's commit (main stream) has read the stand-by buffer
-            with torch.cuda.stream(self.side):          # single GPU: the commit is earlier work of the side stream itself
+        if self.reducer is not None:
+            # data parallel: the commit of the stand-by dropout bits is part of the Adam graph on the main stream; the next
+            # bits are drawn beside the forward pass by two plain launches on the side stream (a graph of their own would
+            # delay the start of the forward graph behind it)
+            if graphs is None:
                 self._pre()
+            elif gp:
+                self.side.wait_event(self.ev_done)
+                with torch.cuda.stream(self.side):
+                    self._pre()
         for p in range(self.K):
             if gm is None:
                 self._main(p)
@@ -282,12 +285,23 @@ class PipelinedTrainStep:
                 gw[p].replay()
                 if exchange:
                     self._exchange(p)
+        if self.reducer is None:
+            # the optimizer step was part of the last leaf graph.  The next step's dropout bits follow it on the side stream
+            # as two plain launches AFTER the point the main stream joins: they run inside the start-up latency of the next
+            # step's first graph without that graph waiting for them
+            if gw is None:
+                self._pre()
+                return
+            self.ev_done.record(self.side)
+            main.wait_event(self.ev_done)
+            if gp:
+                with torch.cuda.stream(self.side):
+                    self._pre()
+            return
         main.wait_stream(self.side)
         for h in self._handles:
             self.reducer.finish(h)
         self._handles.clear()
-        if self.reducer is None:
-            return                                      # the optimizer step was part of the last leaf graph
         if gc is None:
             self._adam()
         else:
