@@ -521,3 +521,36 @@ def test_checkpoint_interchange_and_resume(dev, tmp_path):
     oe.load_state_dict(od.state_dict())
     assert int(oe._step.item()) == 4
     torch.testing.assert_close(oe._m[:100].cpu(), torch.cat([s["exp_avg"].reshape(-1) for s in od.state_dict()["state"].values()])[:100].cpu())
+
+
+def test_pipelined_step_draws_dropout_bits_one_step_ahead(dev):
+    """mask_ahead protocol of the pipelined step with dropout on: the keep bits a step uses are the ones drawn during the
+    previous step (stand-by buffer copied over the live one after the step's last reader), fresh bits are drawn every
+    step, their keep rate is 1 - p, and the loss stays finite and falls."""
+    from dm_amd.optimizer import FusedAdam
+    from dm_amd.runtime import graphs
+    torch.manual_seed(7)
+    m = dm_ddpm.DDPM(dm_unets.BaseUNet, stages_channels=[32, 64, 128, 256], expand_factor=2, drop_p=0.2, T=120, beta=0.25,
+                     t_embed_dim=32, activation="gelu", base_groups_norm=4, initializer="he_normal", dtype=None,
+                     is_conditional=False, img_channels=1, reconstruction_method="mse", latent_dim=512, device=dev).to(dev)
+    m.train()
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    x0 = (hash_uniform((8, 1, 32, 32), 5) * 2 - 1).to(dev)
+    step = graphs.PipelinedTrainStep(m, ELBOLoss("mse"), opt, x0, None, phases=4)
+    eng = m.model._get_engine()
+    assert eng.mask_ahead and eng._mask_key is not None
+    live, ahead = eng._mask_bufs[eng._mask_key]
+    losses = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        standby = ahead.clone()
+        losses.append(step.replay().item())
+        torch.cuda.synchronize()
+        assert torch.equal(live, standby), "the step's stand-by bits did not become the live ones"
+        assert not torch.equal(ahead, standby), "no fresh bits were drawn"
+    bits = torch.stack([(live >> j) & 1 for j in range(8)]).float().mean().item()
+    assert abs(bits - 0.8) < 0.01, bits
+    assert all(math.isfinite(v) for v in losses)
+    for _ in range(40):
+        last = step.replay().item()
+    assert last < losses[0]
