@@ -1,4 +1,4 @@
 set -e
-for mx in 0 64 128 100000; do
-  echo "gnb max cout=$mx: $(DDPM_GNB_MAX=$mx timeout -k 10 200 python -u bench.py --no-sample --no-cpu --no-roofline --steps 60 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"])')"
-done
+for tps in 4 8 16; do for tl in 2 4; do
+  echo "tps=$tps last=$tl: $(DDPM_TPS=$tps DDPM_TPS_LAST=$tl timeout -k 10 200 python -u bench.py --no-sample --no-cpu --no-roofline --steps 60 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"])')"
+done; done
