@@ -89,3 +89,29 @@ def test_pil_resampling_tables_reproduce_pil():
         t = np.stack([np.clip(((1 << 21) + (t[vb[y, 0]:vb[y, 0] + vb[y, 1]] * vc[y, :vb[y, 1]].astype(np.int64)[:, None]).sum(0)) >> 22, 0, 255)
                       for y in range(h)], axis=0)
         assert np.array_equal(t, ref)
+
+
+def test_act_backward_split_choice():
+    """host logic of the streaming activation backward: the number of pixel ranges per image divides H*W, grows with the
+    image, and is 0 (= use the GroupNorm kernel) for channel counts the kernel does not take"""
+    import torch
+    from dm_amd.runtime import ops
+    for h, w, c in [(32, 32, 32), (16, 16, 64), (6, 10, 16), (64, 64, 32), (1, 1, 8), (128, 128, 32)]:
+        p = ops.act_backward_splits(torch.empty(2, h, w, c))
+        assert p >= 1 and (h * w) % p == 0 and p <= 64
+    assert ops.act_backward_splits(torch.empty(2, 64, 64, 32)) > ops.act_backward_splits(torch.empty(2, 8, 8, 32))
+    for c in (4, 24, 128, 256):
+        assert ops.act_backward_splits(torch.empty(1, 8, 8, c)) == 0
+
+
+def test_timestep_oracle_is_uniform():
+    """the numpy restatement of the in-kernel timestep draw covers 1..T evenly (chi-square well inside the 99.9 % bound)"""
+    import numpy as np
+    from oracle.philox import sample_timesteps
+    T, n = 120, 240000
+    t = sample_timesteps(n, T, 123456789, 3)
+    counts = np.bincount(t, minlength=T + 1)[1:]
+    assert counts.min() > 0
+    chi2 = float(((counts - n / T) ** 2 / (n / T)).sum())
+    assert chi2 < 180.0, chi2                      # 119 degrees of freedom: mean 119, 99.9 % quantile ~ 173
+    assert not np.array_equal(t[:1000], sample_timesteps(1000, T, 123456790, 3))
