@@ -80,6 +80,40 @@ def cpu_baseline(channels, size, batch, steps):
                          "sample": f"{ssteps} sampling steps of batch {batch}, extrapolated to the 120-step chain"}}
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh processes of this script, one per GPU, with the
+    rendezvous environment torch.distributed reads (the reference spawns one process per GPU the same way,
+    train_diff.py:114-126 there).  Runs before this process has touched the GPU; the children inherit stdout, so rank 0's
+    JSON line is the job's.  Returns the first non-zero exit status."""
+    import socket
+    import subprocess
+    if n < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if "--dry-launch" not in argv and n > have:
+        sys.exit(f"bench.py: --gpus {n} but this node has {have} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live and not rc:
+        time.sleep(0.05)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                rc = rc or p.returncode
+    for p in live:                           # a failed rank leaves the others waiting in a collective: end exactly those children
+        p.kill()
+        p.wait()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +135,16 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", default="", help="write a per-launch-shape timing table of the roofline pass to this file")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher check: every rank prints its rendezvous environment and exits (no GPU work)")
     a = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.dry_launch):
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", 1)) != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} disagrees with WORLD_SIZE={os.environ.get('WORLD_SIZE', 1)} "
+                 "(one rank per GPU: launch with --nproc-per-node equal to --gpus, or let bench.py start the ranks itself)")
+    if a.dry_launch:
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        return
     # libraries (the collective library's version banner, for one) write to stdout: keep the real stdout for the one JSON
     # line and send everything else to stderr
     sys.stdout.flush()
@@ -168,12 +211,13 @@ def main():
     loss = step.replay().item()
     train_ips = a.batch * world * a.steps / dt
 
+    shaped = {(32, 1): " (FashionMNIST-shaped)", (64, 3): " (Flowers102-shaped)"}.get((a.size, a.channels), "")
     out = {
         "metric": "train imgs/sec (q_sample + UNet fwd + ELBO + bwd + Adam step), sampled imgs/sec reported alongside",
         "value": train_ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"DDPM train step, {a.size}x{a.size}x{a.channels} (FashionMNIST-shaped), batch {a.batch}/GPU, "
+        "config": {"workload": f"DDPM train step, {a.size}x{a.size}x{a.channels}{shaped}, batch {a.batch}/GPU, "
                                f"stages [32,64,128,256], T=120, drop_p=0.1, Adam (lr 1e-3), gradient_accumulation_steps=1"
                                + (f", self-attention at stages {a.attention_stages}" if a.attention_stages else ""),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph,

@@ -323,6 +323,15 @@ static int launch_conv(const ConvArgs& a, size_t lds, hipStream_t stream) {
     return ddpm_check_launch("conv_mfma");
 }
 
+// Test hook: the tile the next general-kernel launches of this thread must use (0 = choose by shape) and the tile the last
+// one used, both coded wm * 100 + wn * 10 + nt.
+static thread_local int g_force_tile = 0, g_last_tile = 0;
+extern "C" int ddpm_conv_debug_tile(int force) {
+    const int last = g_last_tile;
+    if (force >= 0) g_force_tile = force;
+    return last;
+}
+
 extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DDPM_REQUIRE(d && d->in0 && d->w && d->out, "conv: null pointer");
@@ -361,8 +370,10 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
         if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 32 * c.wm) != 0) { ddpm_set_error("conv: geometry"); return DDPM_EINVAL; }
         const long long blocks = (long long)a.g.tiles_n * a.g.tiles_h * a.g.tiles_w * (co32 / bn32) * a.g.ncls;
         pick = i;
-        if (blocks >= 384) break;
+        if (g_force_tile ? g_force_tile == c.wm * 100 + c.wn * 10 + c.nt : blocks >= 384) break;
+        if (g_force_tile) pick = -1;
     }
+    DDPM_REQUIRE(pick >= 0 || !g_force_tile, "conv: forced tile %d is not available for CoutW=%d, kind %d", g_force_tile, d->CoutW, d->kind);
     DDPM_REQUIRE(pick >= 0, "conv: no tile configuration for CoutW=%d", d->CoutW);
     const Cfg cfg = cands[pick];
     conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 32 * cfg.wm);
@@ -376,6 +387,7 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
 
     const int npix = a.g.NB * a.g.PH * a.g.PW;
     const int bm = 32 * cfg.wm, bn = 32 * cfg.nt * cfg.wn;
+    g_last_tile = cfg.wm * 100 + cfg.wn * 10 + cfg.nt;
     size_t lds = ((size_t)npix * 4 + 15) / 16 * 16 + CONV_MAX_TAPS * 4 + (size_t)npix * CONV_RS + (size_t)a.g.max_taps * bn * CONV_RS;
     const size_t lds_out = (size_t)bm * (bn * 2 + 16);
     if (lds < lds_out) lds = lds_out;

@@ -53,6 +53,9 @@ class DDPM(nn.Module):
             t = torch.arange(1, T + 1)
             g = lambda name: getattr(self, name).detach().to("cpu", torch.float32)
             tab = torch.zeros(T + 1, 8)
+            # row 0: q(x0, t=0) = x0 as in the reference (fw_mean_coef[0] = 1, fw_std[0] = 0); the reverse step and the ELBO
+            # weight are undefined there (nan / inf in the reference's tables) and stay 0
+            tab[0, 0] = 1.0
             tab[1:, 0] = g("sqrt_alphas_bar")[t].flatten()
             tab[1:, 1] = g("sqrt_one_minus_alphas_bar")[t].flatten()
             tab[1:, 2] = (g("one_minus_alphas_bar")[t - 1] * g("x_previous_coef")[t]).flatten()
@@ -76,6 +79,16 @@ class DDPM(nn.Module):
         if not x.is_cuda:
             raise RuntimeError(f"DDPM.{what} runs on the HIP kernels only: tensors must live on an MI355X (cuda) device")
 
+    def _check_t(self, t: Tensor, lo: int, what: str) -> None:
+        """The kernels index the per-timestep table with t unchecked; the reference's table lookup raises IndexError for an
+        out-of-range timestep.  Checked on the host (one small device-to-host read) except inside a graph capture, whose
+        timesteps come from this module's own generators."""
+        if torch.cuda.is_current_stream_capturing() or t.numel() == 0:
+            return
+        mn, mx = (int(v) for v in torch.aminmax(t))
+        if mn < lo or mx > self.T:
+            raise IndexError(f"DDPM.{what}: timesteps must lie in [{lo}, {self.T}], got [{mn}, {mx}]")
+
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def q(self, x_0: Tensor, T: Tensor, noise: Optional[Tensor] = None) -> Tensor:
@@ -84,6 +97,7 @@ class DDPM(nn.Module):
         x_0 = x_0.float().contiguous()
         n, c, h, w = x_0.shape
         t = T.to(torch.long).contiguous()
+        self._check_t(t, 0, "q")
         out = torch.empty_like(x_0)
         tab = self.schedule_table(x_0.device)
         if noise is not None:
@@ -122,6 +136,7 @@ class DDPM(nn.Module):
         x_t = x_t.float().contiguous()
         x0_predicted = x0_predicted.float().contiguous()
         t = T.to(torch.long).contiguous()
+        self._check_t(t, 1, "reverse_q")
         n = x_t.shape[0]
         chw = x_t.numel() // n
         if out is None:
@@ -160,8 +175,12 @@ class DDPM(nn.Module):
     @torch.no_grad()
     def sample(self, N: int, shape: Union[int, Tuple[int, int]] = (64, 64)):
         """List of N PIL images, as the reference returns (ddpm.py:147-165, utils/other_utils.py:14-37 there)."""
-        x = self.sample_tensor(N, shape)
-        x = ((x + 1) / 2).clamp_(0.0, 1.0)
         from PIL import Image
-        arr = (x.mul(255).round().to(torch.uint8).permute(0, 2, 3, 1)).cpu().numpy()
+        arr = self.to_uint8(self.sample_tensor(N, shape)).permute(0, 2, 3, 1).cpu().numpy()
         return [Image.fromarray(a[..., 0] if a.shape[-1] == 1 else a) for a in arr]
+
+    @staticmethod
+    def to_uint8(x: Tensor) -> Tensor:
+        """The byte image of a sampled tensor: (x + 1) / 2 clamped to [0, 1] (ddpm.py:163-165, utils/other_utils.py:14-37
+        there), then torchvision's to_pil_image arithmetic, `pic.mul(255).byte()`: a truncation, not a rounding."""
+        return ((x + 1) / 2).clamp_(0.0, 1.0).mul(255).to(torch.uint8)

@@ -19,8 +19,14 @@ class FusedAdam(torch.optim.Optimizer):
 
     On the first step every parameter is re-pointed to a view of one flat buffer (values preserved), so state_dict(),
     .grad, DDP and EMA wrappers keep working on the same nn.Parameter objects.  The step counter and the learning
-    rate live in device memory: the step is capturable in a HIP graph and an LR scheduler can update the rate
-    with `set_lr` without re-capturing."""
+    rate live in device memory, so the step is capturable in a HIP graph.  A torch LR scheduler writes
+    param_groups[0]["lr"] (the reference trainer always attaches CosineAnnealingLR, base_trainer.py:109-115 there): every
+    eager step() compares that value with the one the device scalar holds and refreshes the scalar when it moved.  A
+    captured step() cannot look at host values when it is replayed: call sync_lr() (or set_lr) after scheduler.step();
+    the graph drivers in runtime/graphs.py do so before every replay.
+
+    One hyper-parameter set for all parameters: several param groups are accepted only when their lr, betas, eps and
+    weight_decay agree."""
 
     def __init__(self, params: Iterable[Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  ema_decay: Optional[float] = None, **_ignored):
@@ -28,6 +34,23 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.ema_decay = ema_decay
         self._flat = None
+        self._lr_host = None
+        self._check_groups()
+
+    def _check_groups(self) -> None:
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if g[k] != g0[k]:
+                    raise ValueError(f"FusedAdam applies one hyper-parameter set to every parameter: param groups differ in {k!r} "
+                                     f"({g0[k]} vs {g[k]})")
+
+    def add_param_group(self, param_group) -> None:
+        super().add_param_group(param_group)
+        if len(self.param_groups) > 1:
+            self._check_groups()
+        if getattr(self, "_flat", None) is not None:
+            raise RuntimeError("FusedAdam: parameters cannot be added after the first step (the flat buffer is already laid out)")
 
     # -------------------------------------------------------------------------------------------------
     def _params(self) -> List[Tensor]:
@@ -52,13 +75,27 @@ class FusedAdam(torch.optim.Optimizer):
         self._g = torch.zeros_like(flat)
         self._ema = flat.clone() if self.ema_decay is not None else None
         self._step = torch.zeros(1, device=dev, dtype=torch.long)
-        self._lr = torch.full((1,), float(self.param_groups[0]["lr"]), device=dev, dtype=torch.float32)
+        self._lr_host = float(self.param_groups[0]["lr"])
+        self._lr = torch.full((1,), self._lr_host, device=dev, dtype=torch.float32)
 
     def set_lr(self, lr: float) -> None:
         for g in self.param_groups:
             g["lr"] = lr
-        if self._flat is not None:
+        self.sync_lr()
+
+    def sync_lr(self) -> None:
+        """Bring the device-resident learning rate up to date with param_groups (what an LR scheduler writes).  One host
+        comparison; a fill kernel on the current stream only when the value moved.  Not callable inside a graph capture."""
+        if self._flat is None:
+            return
+        if len(self.param_groups) > 1:
+            self._check_groups()
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdam: the learning rate changed during a graph capture; call sync_lr() before capturing")
             self._lr.fill_(lr)
+            self._lr_host = lr
 
     def ema_parameters(self) -> List[Tensor]:
         """Views of the EMA weights, in parameter order (None unless ema_decay was given)."""
@@ -85,6 +122,8 @@ class FusedAdam(torch.optim.Optimizer):
         if self._flat is None:
             self._flatten()
         ps = self._params()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
         g = self._flat_grad(ps)
         grp = self.param_groups[0]
         b1, b2 = grp["betas"]
@@ -134,7 +173,8 @@ class FusedAdam(torch.optim.Optimizer):
             if len(set(steps)) != 1:
                 raise ValueError("FusedAdam keeps one step counter: the checkpoint's parameters are at different steps")
             self._step.fill_(steps[0])
-        self._lr.fill_(float(self.param_groups[0]["lr"]))
+        self._lr_host = float(self.param_groups[0]["lr"])
+        self._lr.fill_(self._lr_host)
         if ema is not None and self._ema is not None:
             for dst, src in zip(self.ema_parameters(), ema):
                 dst.copy_(src)

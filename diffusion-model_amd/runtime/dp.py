@@ -1,7 +1,8 @@
 """Data-parallel gradient exchange: one process per GPU, flat all-reduces over RCCL (xGMI), overlapped with backward.
 
-The reference shards the batch with torch DDP under `accelerate` (train_ddpm.py:24-80, base_trainer.py:48-58,151-158
-there): per-parameter autograd hooks feed 25 MB buckets.  Here the whole denoiser backward is one autograd node whose
+The reference wraps the model in stock torch DistributedDataParallel (base_trainer.py:95-100 there; one process per GPU
+spawned by train_diff.py:114-126, NCCL group set up in experiments_setup/utils.py:170-187): per-parameter autograd hooks
+feed 25 MB buckets.  Here the whole denoiser backward is one autograd node whose
 350 parameter gradients come out as views of ONE flat fp32 buffer (27 MB for the 6.86 M-parameter network), so the
 exchange is a single collective on that buffer with no packing pass; averaging is folded into the collective (AVG)
 where the backend has it.  xGMI rings are per-link bound, so few large messages beat many small ones: `bucket_bytes`

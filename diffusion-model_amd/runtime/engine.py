@@ -153,7 +153,7 @@ class UNetEngine:
         self.grads: Optional[GradStore] = None
         self.seed: Optional[Tensor] = None
         self._mask_offsets: Dict[Tuple[int, int, int], Tuple[Tensor, List[int], int]] = {}
-        self.mask_ahead = False        # keep bits drawn one step ahead by the driver (see _make_masks)
+        self.mask_ahead = False        # set by a driver that draws keep bits one step ahead (it passes mask_ahead=True to forward)
         self._zero_arena: Optional[Tensor] = None
         self._zero_cursor = self._zero_need = 0
         self._mask_bufs: Dict = {}
@@ -175,6 +175,7 @@ class UNetEngine:
                                         # one phase per stage, so
                                         # that a driver can run a phase's leaf work (weight gradients, exchange) beside the next phase
         self._reduce_tables: Dict[Tuple, Tuple[Tensor, List[int], List[int], int]] = {}
+        self.external_zero = False      # gradient accumulation: backward passes add to the gradient sums, the driver clears them
 
     @property
     def bucketed(self) -> bool:
@@ -207,12 +208,14 @@ class UNetEngine:
             sir(co, hh, ww); sir(co, hh, ww)
         return sizes
 
-    def _make_masks(self, key, sizes_fn: Callable[[], List[int]], device) -> List[Tensor]:
+    def _make_masks(self, key, sizes_fn: Callable[[], List[int]], device, ahead: bool = False) -> List[Tensor]:
         """One keep-bit buffer for all dropout sites of a pass (element counts from sizes_fn, cached under key).
 
-        mask_ahead mode (the pipelined training step): the buffer is persistent and is NOT filled here; the driver draws
-        the next step's bits into a second buffer while this step computes (generate_masks) and copies them over once
-        the step's last reader is done (commit_masks).  The first call of a shape fills the buffer directly."""
+        ahead = True (only the pipelined training step asks for it, per call): the buffer is persistent and is NOT filled
+        here; the driver draws the next step's bits into a second buffer while this step computes (generate_masks) and
+        copies them over once the step's last reader is done (commit_masks).  The first call fills the buffer directly.
+        Every other caller (the module's autograd path, block programs, other shapes) gets freshly drawn bits, also on an
+        engine a pipelined driver is attached to."""
         if key not in self._mask_offsets:
             sizes = sizes_fn()
             nbytes = [(s // 8 + 3) // 4 * 4 for s in sizes]
@@ -223,7 +226,10 @@ class UNetEngine:
         offs_dev, offs, nsites = self._mask_offsets[key]
         if self.seed is None:
             self.seed = torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.long)
-        if self.mask_ahead:
+        if ahead:
+            if self._mask_key is not None and key != self._mask_key:
+                raise RuntimeError(f"the pipelined step draws its dropout bits one step ahead for batch shape {self._mask_key[:3]}; "
+                                   f"it was called with {key[:3]} (build a new step for a new shape)")
             if key not in self._mask_bufs:
                 self._mask_bufs[key] = (torch.empty(offs[-1], device=device, dtype=torch.uint8), torch.empty(offs[-1], device=device, dtype=torch.uint8))
                 self._mask_seed = self.seed ^ 0x5DEECE66D
@@ -257,7 +263,8 @@ class UNetEngine:
         live.copy_(ahead)
         hip.call("ddpm_bump_seed", hip.ptr(self.seed), hip.stream())
 
-    def _open(self, params: Dict[str, Tensor], n: int, dev, rkey, train: bool, record: bool, masks, site_sizes, taps=None):
+    def _open(self, params: Dict[str, Tensor], n: int, dev, rkey, train: bool, record: bool, masks, site_sizes, taps=None,
+              mask_ahead: bool = False):
         """Start a pass: returns a namespace of the fused-unit builders (conv_unit, dw_unit, sir, embed, ...) bound to this
         pass's tape, dropout masks and partial-sum workspace.  rkey identifies the program + shape (workspace layout cache);
         site_sizes() lists the element counts of the dropout sites in call order."""
@@ -269,7 +276,7 @@ class UNetEngine:
         tape: Optional[List[Callable[[], None]]] = [] if record else None
         use_drop = train and sp.drop_p > 0.0
         if use_drop and masks is None:
-            masks = self._make_masks(rkey, site_sizes, dev)
+            masks = self._make_masks(rkey, site_sizes, dev, mask_ahead)
         mscale = 1.0 / (1.0 - sp.drop_p) if use_drop else 1.0
         site = [0]
         P = params
@@ -678,9 +685,9 @@ class UNetEngine:
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, params: Dict[str, Tensor], x: Tensor, t: Tensor, train: bool, record: bool,
-                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None):
+                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None, mask_ahead: bool = False):
         """x: NCHW fp32 on the GPU, t: int64 [N].  Returns (out NCHW fp32, tape or None).
-        train enables dropout; record keeps what backward needs."""
+        train enables dropout; record keeps what backward needs; mask_ahead: see _make_masks."""
         sp = self.spec
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == sp.img_channels
         x = x.contiguous()
@@ -690,7 +697,7 @@ class UNetEngine:
         if h % (1 << nst) or w % (1 << nst):
             raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
         dev = x.device
-        c_ = self._open(params, n, dev, (n, h, w, self.phases), train, record, masks, lambda: self._site_sizes(n, h, w), taps)
+        c_ = self._open(params, n, dev, (n, h, w, self.phases), train, record, masks, lambda: self._site_sizes(n, h, w), taps, mask_ahead)
         P, G, wc, tape, late = c_.P, c_.G, c_.wc, c_.tape, c_.late
         conv_unit, sir, embed, wgrad, part_alloc, part_entries, tap, finish = (c_.conv_unit, c_.sir, c_.embed, c_.wgrad, c_.part_alloc,
                                                                                c_.part_entries, c_.tap, c_.finish)
@@ -907,7 +914,8 @@ class UNetEngine:
         tape, out_holder, _, marks = ctx
         self._cur_tps = self.wgrad_tiles_last if (marks and phase == len(marks)) else self.wgrad_tiles_per_split
         if phase == 0:
-            self.grads.zero()
+            if not self.external_zero:
+                self.grads.zero()
             if self._zero_arena is not None:
                 self._zero_arena.zero_()
             self._zero_cursor = self._zero_need = 0
@@ -916,6 +924,11 @@ class UNetEngine:
         seg = len(bounds) - 2 - phase
         for fn in reversed(tape[bounds[seg]:bounds[seg + 1]]):
             fn()
+
+    def grads_zero(self) -> None:
+        """Clear the gradient sums (external_zero mode: the driver decides when an accumulation window starts)."""
+        if self.grads is not None:
+            self.grads.zero()
 
     def backward_flush(self, ctx, phase: int) -> bool:
         """The leaf work of a phase; after it the gradients of the phase's parameters are final in the kernel-layout

@@ -87,6 +87,8 @@ class GraphedTrainStep:
         self._back()
 
     def replay(self) -> Tensor:
+        if hasattr(self.optimizer, "sync_lr"):
+            self.optimizer.sync_lr()            # an LR scheduler's new value reaches the captured Adam through device memory
         if self.graph is None:
             self._body()
         else:
@@ -127,9 +129,21 @@ class PipelinedTrainStep:
     Needs this package's DDPM/BaseUNet, ELBOLoss and FusedAdam.  Parameter .grad tensors are bound once to views of the
     engine's persistent flat gradient buffer.  Copy a new batch into `self.x0` before each replay()."""
 
-    def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer=None, *, phases: int = 4, use_graph: bool = True, warmup: int = 3):
+    def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer=None, *, phases: int = 4, use_graph: bool = True, warmup: int = 3,
+                 gradient_accumulation_steps=1, t: Optional[Tensor] = None, noise: Optional[Tensor] = None):
+        """gradient_accumulation_steps = k > 1 (the reference trainer's default is 3, base_trainer.py:43,215-235 there):
+        gradients of k consecutive replays are summed without any 1/k scaling, the optimizer steps on every k-th replay
+        (or on replay(last=True), the trainer's "last batch of the epoch" case) and the sum restarts after it; with a
+        reducer the exchange happens once, on the summed gradients (same numbers as the reference's exchange per
+        micro-batch, a third of the traffic).  The value may arrive as a string (CLI passthrough).
+        t / noise: static device tensors (int64 [N] / like x0) that replace the in-kernel draws of the per-image timestep
+        and of the forward-noising noise, for parity checks; overwrite them between replays."""
         self.core = ddpm.module if hasattr(ddpm, "module") else ddpm
         self.criterion, self.optimizer, self.reducer, self.x0 = criterion, optimizer, reducer, x0
+        self.t_in, self.noise_in = t, noise
+        self.accum = max(1, int(gradient_accumulation_steps))
+        self._sep_adam = reducer is not None or self.accum > 1      # the optimizer step is a graph of its own on the main stream
+        self._micro = 0
         self.unet = self.core.model
         self.eng = self.unet._get_engine()
         # the kernel-layout weight copies are refreshed right after the optimizer step (see _adam), not at the head of the
@@ -139,6 +153,7 @@ class PipelinedTrainStep:
         if int(phases) < 2:
             raise ValueError("phases must be 2, 4 or larger (= one phase per stage)")
         self.eng.phases = int(phases)
+        self.eng.external_zero = self.accum > 1     # the driver clears the gradient sums (every k-th replay), not the backward pass
         import os
         self.eng.wgrad_tiles_last = int(os.environ.get("DDPM_TPS_LAST", self.eng.wgrad_tiles_last))
         self.eng.wgrad_tiles_per_split = int(os.environ.get("DDPM_TPS", self.eng.wgrad_tiles_per_split))
@@ -175,7 +190,7 @@ class PipelinedTrainStep:
                     self._leaf(p)
                 gw.append(g)
             gc = None
-            if self.reducer is not None:
+            if self._sep_adam:
                 gc = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gc, capture_error_mode="thread_local"):
                     self._adam()
@@ -191,10 +206,10 @@ class PipelinedTrainStep:
             return
         from . import hip
         core, n = self.core, self.x0.shape[0]
-        t = core.sample_timesteps(n, self.x0.device)
-        x_t = core.q(self.x0, t)
+        t = self.t_in if self.t_in is not None else core.sample_timesteps(n, self.x0.device)
+        x_t = core.q(self.x0, t, noise=self.noise_in)
         params = dict(zip(self.unet._param_names, self.unet.parameters()))
-        pred, self._ctx = self.eng.forward(params, x_t, t, train=self.unet.training, record=True)
+        pred, self._ctx = self.eng.forward(params, x_t, t, train=self.unet.training, record=True, mask_ahead=True)
         table = self.criterion._table(core, pred.device)
         chw = pred.numel() // n
         flags = (int(self.criterion.bce), int(bool(self.criterion.use_elbo)))
@@ -223,7 +238,7 @@ class PipelinedTrainStep:
                 for name, prm in zip(self.unet._param_names, self.unet.parameters()):
                     prm.grad = views[name]
                 self._bound = True
-            if self.reducer is None:
+            if not self._sep_adam:
                 # single GPU: nothing comes between the last gradient and the optimizer, so the update rides at the end
                 # of this graph instead of paying a graph start of its own on the main stream
                 self._adam()
@@ -243,7 +258,7 @@ class PipelinedTrainStep:
 
     def _exchange(self, p: int):
         """called with the side stream current, right after W_p was queued on it"""
-        if self.reducer is None:
+        if self.reducer is None or not self._final:
             return
         flat = self.eng.grads.flat_t
         last = p == self.K - 1
@@ -254,10 +269,14 @@ class PipelinedTrainStep:
                 self._handles.append(self.reducer.start_range(flat, *self._ranges[0]))
             self._handles.append(self.reducer.start_range(flat, *self._ranges[1]))
 
-    def _run(self, graphs, exchange: bool = True):
+    def _run(self, graphs, exchange: bool = True, last: bool = False):
         main = torch.cuda.current_stream()
         gm, gw, gc, gp = graphs if graphs is not None else (None, None, None, None)
-        if self.reducer is not None:
+        self._final = last or (self._micro + 1) % self.accum == 0
+        if self.accum > 1 and self._micro % self.accum == 0:
+            self.eng.grads_zero()                       # a plain fill ahead of the first graph: the sums restart here
+        self._micro = 0 if self._final else self._micro + 1
+        if self._sep_adam:
             # data parallel: the commit of the stand-by dropout bits is part of the Adam graph on the main stream; the next
             # bits are drawn beside the forward pass by two plain launches on the side stream (a graph of their own would
             # delay the start of the forward graph behind it)
@@ -285,7 +304,7 @@ class PipelinedTrainStep:
                 gw[p].replay()
                 if exchange:
                     self._exchange(p)
-        if self.reducer is None:
+        if not self._sep_adam:
             # the optimizer step was part of the last leaf graph.  The next step's dropout bits follow it on the side stream
             # as two plain launches AFTER the point the main stream joins: they run inside the start-up latency of the next
             # step's first graph without that graph waiting for them
@@ -302,18 +321,24 @@ class PipelinedTrainStep:
         for h in self._handles:
             self.reducer.finish(h)
         self._handles.clear()
-        if gc is None:
+        if not self._final:
+            self.eng.commit_masks()                     # a micro-step that only accumulates: no update, fresh dropout bits
+        elif gc is None:
             self._adam()
         else:
             gc.replay()
+        if gc is not None:
             self.ev_done.record(main)
 
     def local_body(self):
         """one eager step without the exchange (per-kernel timing on one rank must not enter a collective)"""
         self._run(None, exchange=False)
 
-    def replay(self) -> Tensor:
-        self._run(self.graphs)
+    def replay(self, last: bool = False) -> Tensor:
+        """One micro-step on the batch in self.x0; last=True forces the optimizer step (the trainer's last batch of an epoch)."""
+        if hasattr(self.optimizer, "sync_lr"):
+            self.optimizer.sync_lr()            # an LR scheduler's new value reaches the captured Adam through device memory
+        self._run(self.graphs, last=last)
         return self.loss[0]
 
 

@@ -116,6 +116,7 @@ _PROTOS = {
     "ddpm_act_backward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "ddpm_prepare_images": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
+    "ddpm_conv_debug_tile": ([_i], _i),
     "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_conv_gnb_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),

@@ -145,6 +145,12 @@ int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d);
 
 /* y = act(conv(x) + bias) [* mask] [+ res] for every kind above. */
 int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream);
+/* Test hook (no counterpart in the reference): the general implicit-GEMM kernel picks its workgroup tile from the problem
+ * size, so small test problems would never reach the tiles that large batches run on.  force > 0 (coded
+ * wm * 100 + wn * 10 + nt: wm x wn waves, nt 32-channel column blocks per wave) makes the following ddpm_conv_forward calls
+ * of the calling thread use that tile or fail; 0 restores the automatic choice; -1 changes nothing.  Returns the code of the
+ * tile the thread's last general-kernel launch used (0 if none). */
+int ddpm_conv_debug_tile(int force);
 
 /* ---- GroupNorm + activation (+ dropout mask, + residual) on NHWC bf16 (groupnorm.hip) ------------- */
 

@@ -1,6 +1,6 @@
 """Data-parallel gradient exchange on two CPU ranks (gloo): the flat-view fast path, the gather/scatter path, parameter
-broadcast and the sampling shard split.  Mirrors what the reference gets from accelerate's DDP wrapper
-(base_trainer.py:48-58,151-158 there): after the exchange every rank holds the mean gradient."""
+broadcast and the sampling shard split.  Mirrors what the reference gets from torch's DistributedDataParallel wrapper
+(base_trainer.py:95-100 there): after the exchange every rank holds the mean gradient."""
 import os
 import socket
 

@@ -115,3 +115,23 @@ def test_timestep_oracle_is_uniform():
     chi2 = float(((counts - n / T) ** 2 / (n / T)).sum())
     assert chi2 < 180.0, chi2                      # 119 degrees of freedom: mean 119, 99.9 % quantile ~ 173
     assert not np.array_equal(t[:1000], sample_timesteps(1000, T, 123456790, 3))
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` starts N ranks itself (train_diff.py:114-126 of the reference spawns one process per GPU);
+    a --gpus that disagrees with an existing WORLD_SIZE is refused instead of silently running one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["RANK"])
+    assert [d["RANK"] for d in rows] == ["0", "1"] and [d["LOCAL_RANK"] for d in rows] == ["0", "1"]
+    assert all(d["WORLD_SIZE"] == "2" and d["MASTER_ADDR"] == "127.0.0.1" for d in rows)
+    assert rows[0]["MASTER_PORT"] == rows[1]["MASTER_PORT"]
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--dry-launch"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
