@@ -12,6 +12,8 @@
 #include "common.h"
 #include "ddpm_hip.h"
 
+#include <mutex>
+
 struct GnArgs {
     const bf16* x;             // [N][HW][C] raw convolution output
     const float* gamma;        // [C]
@@ -666,4 +668,64 @@ extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_
     }
     GN_DISPATCH(gn_bwd_kernel)
     return ddpm_check_launch("gn_backward");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The forward pass for callers that cannot bring (or allocate) a workspace: the split path's partial sums live in a
+// file-scope device array instead of ddpm_gn_desc.scratch.  Every GPU the library runs on holds its own copy of the array
+// (at its own address) until the process ends.  The array's name is only a host-side handle: its device address is asked
+// for once per device, with that device current, and kept.
+#define GN_STATIC_FLOATS (1 << 20)                                   /* 4 MiB per GPU */
+static __device__ __align__(256) float gn_static_scratch[GN_STATIC_FLOATS];
+
+#define GN_MAX_DEVICES 64
+static float* g_static_ptr[GN_MAX_DEVICES];                          // device address of gn_static_scratch, per device
+static std::mutex g_static_mu;
+
+static int gn_static_pointer(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEVICES) {
+        ddpm_set_error("gn_forward_static: cannot tell the current device (%d)", dev);
+        return DDPM_EHIP;
+    }
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (!g_static_ptr[dev]) {
+        float* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(gn_static_scratch));
+        if (e != hipSuccess || !p) {
+            ddpm_set_error("gn_forward_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return DDPM_EHIP;
+        }
+        g_static_ptr[dev] = p;
+    }
+    *out = g_static_ptr[dev];
+    return DDPM_OK;
+}
+
+extern "C" int64_t ddpm_gn_static_scratch_floats(void) { return GN_STATIC_FLOATS; }
+
+extern "C" int ddpm_gn_act_forward_static(const ddpm_gn_desc* d, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GnArgs a;
+    if (int rc = gn_prepare(a, d, "gn_forward_static")) return rc;
+    const long long need = gn_scratch_need(a, false);
+    DDPM_REQUIRE(need <= GN_STATIC_FLOATS,
+                 "gn_forward_static: this shape needs %lld floats of partial sums, the built-in workspace holds %d "
+                 "(N * groups * pixel splits * 2; use ddpm_gn_act_forward with a workspace of your own)", need, GN_STATIC_FLOATS);
+    float* ws = nullptr;
+    if (int rc = gn_static_pointer(&ws)) return rc;
+    ddpm_gn_desc t = *d;
+    t.scratch = ws;                        // the device address, never the array's name
+    t.scratch_floats = GN_STATIC_FLOATS;
+    a.scratch = ws;
+    if (gn_use_split(a, &t, false)) {
+        // every partial-sum slot the apply launch reads is written by the statistics launch before it: nothing in the
+        // workspace has to start at zero, whatever an earlier (larger) call left there
+        const int units = a.N * (a.C / a.SC) * a.P;
+        if (a.G > 0) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        hipLaunchKernelGGL(gn_fwd_split_apply_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        return ddpm_check_launch("gn_forward_static");
+    }
+    GN_DISPATCH(gn_fwd_kernel)
+    return ddpm_check_launch("gn_forward_static");
 }

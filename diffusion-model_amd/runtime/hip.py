@@ -122,6 +122,8 @@ _PROTOS = {
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_scratch_floats": ([C.POINTER(GnDesc), _i], _i64),
+    "ddpm_gn_act_forward_static": ([C.POINTER(GnDesc), _vp], _i),
+    "ddpm_gn_static_scratch_floats": ([], _i64),
     "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),

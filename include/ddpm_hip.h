@@ -183,6 +183,15 @@ int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream);
 int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
 /* floats of `scratch` the forward (backward = 0) or backward (1) call would use for this shape; 0 = none; -1 on error */
 int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward);
+/* ddpm_gn_act_forward for callers that cannot allocate or pass a workspace (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arithmetic and results as
+ * ddpm_gn_act_forward given a sufficient workspace; d->scratch / d->scratch_floats are ignored: the partial sums of the
+ * many-workgroup path live in a device array built into the library, ddpm_gn_static_scratch_floats() floats (4 MiB) on every
+ * GPU the library runs on, held until the process ends.  A shape that needs more (N * groups * pixel splits * 2 floats) is
+ * rejected with an error.  The call allocates nothing.  All calls on one GPU share that array: calls that overlap on one GPU
+ * (different streams) race; calls on one stream, or ordered by events, do not. */
+int ddpm_gn_act_forward_static(const ddpm_gn_desc* d, ddpm_stream_t stream);
+int64_t ddpm_gn_static_scratch_floats(void);
 
 /* ---- depthwise 3x3 convolution, stride 1, padding 1, NHWC bf16 (dwconv.hip) ---------------------- */
 
