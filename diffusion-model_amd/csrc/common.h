@@ -90,6 +90,21 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
     }
 }
 
+// Runs f(integral_constant<int, A>) with A = the activation code when it is one of the hot ones (gelu, silu, none), so that
+// act_fwd / act_bwd inside f fold to straight-line code; every other code runs f with A = -1, where the callee keeps the
+// runtime switch.  A loop over elements that calls act_fwd(x, act) with a runtime code expands the whole switch (tanhf and
+// expf bodies included) around every element: several hundred instructions each and an instruction stream that no longer
+// fits the instruction cache.
+template <int A> struct ActTag { static constexpr int value = A; };
+template <typename F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
+    if (act == ACT_GELU) f(ActTag<ACT_GELU>{});
+    else if (act == ACT_SILU) f(ActTag<ACT_SILU>{});
+    else if (act == ACT_NONE) f(ActTag<ACT_NONE>{});
+    else f(ActTag<-1>{});
+}
+#define ACT_OF(tag, runtime) (decltype(tag)::value >= 0 ? decltype(tag)::value : (runtime))
+
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based RNG)
 struct Philox4 {
     uint32_t x, y, z, w;

@@ -40,12 +40,14 @@ struct ConvGeom {
     int GH, GW;            // positions per image (per class)
     int SI, SO;            // input / output stride per position
     int dmin_h, dmin_w;    // input offset of a patch's first row / column relative to position*SI
+    int dmax_h, dmax_w;    // largest tap offset relative to position*SI
     int PH, PW;            // patch rows / columns per image tile
     int TH, TW, NB;        // tile: NB images x TH x TW positions
     int tiles_h, tiles_w, tiles_n;
     int ncls;
     int cls_tap_begin[CONV_MAX_CLS + 1];
     int cls_off_h[CONV_MAX_CLS], cls_off_w[CONV_MAX_CLS];
+    int tap_dh[CONV_MAX_TAPS], tap_dw[CONV_MAX_TAPS];   // patch-relative row / column offset of each tap (>= 0)
     int tap_poff[CONV_MAX_TAPS];    // dh*PW + dw : pixel offset inside the patch
     int tap_slice[CONV_MAX_TAPS];   // which [rows][Cin] weight slice the tap multiplies with
     int max_taps;                   // largest tap count of any class
@@ -151,7 +153,8 @@ static inline int conv_geom_init(ConvGeom* g, int kind, int N, int IH, int IW, i
     g->PH = (th - 1) * g->SI + (dmax_h - g->dmin_h) + 1;
     g->PW = (tw - 1) * g->SI + (dmax_w - g->dmin_w) + 1;
     g->tiles_h = (g->GH + th - 1) / th; g->tiles_w = (g->GW + tw - 1) / tw; g->tiles_n = (N + g->NB - 1) / g->NB;
-    for (int j = 0; j < nt; ++j) g->tap_poff[j] = dh[j] * g->PW + dw[j];   // dh/dw are patch-relative (>= 0)
+    for (int j = 0; j < nt; ++j) { g->tap_dh[j] = dh[j]; g->tap_dw[j] = dw[j]; g->tap_poff[j] = dh[j] * g->PW + dw[j]; }   // dh/dw are patch-relative (>= 0)
+    g->dmax_h = dmax_h; g->dmax_w = dmax_w;
     g->tw_shift = ilog2_exact(tw); g->thw_shift = ilog2_exact(tw * th);
     g->pw_magic = div_magic(g->PW); g->phw_magic = div_magic(g->PH * g->PW);
     if (g->NB * g->PH * g->PW >= 65536) return -1;                          // range of the multiply-high division

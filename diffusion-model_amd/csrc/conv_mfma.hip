@@ -17,6 +17,7 @@
 
 int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_small.hip
 int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream);    // conv_thin.hip
+int ddpm_conv_img_try(const ddpm_conv_desc* d, hipStream_t stream, int plain_too);   // conv_img.hip
 
 struct ConvArgs {
     ConvGeom g;
@@ -348,6 +349,8 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
     // 3x3 convolutions on 2x2 / 4x4 images (the deepest stages) have their own kernel
     if (const int rc = ddpm_conv_small_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
+    // whole-image tiles: the unit's GroupNorm (forward) or its backward (data-gradient launches) runs in the same launch
+    if (const int rc = ddpm_conv_img_try(d, stream, 0)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
     DDPM_REQUIRE(!d->gnb_raw, "conv: no fused GroupNorm backward for this shape (ask ddpm_conv_gnb_fusable first)");
     // the image head (a handful of output channels) runs on the vector ALUs
     if (const int rc = ddpm_conv_thin_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;

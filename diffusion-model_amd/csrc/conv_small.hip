@@ -332,8 +332,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
     }
 }
 
-// Whether the GroupNorm backward described by the gnb_* fields can run in the loader of this (data-gradient) launch.
-extern "C" int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d) {
+int ddpm_conv_img_fusable(const ddpm_conv_desc* d, int backward);     // conv_img.hip
+
+static int small_gnb_fusable(const ddpm_conv_desc* d) {
     if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
     if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->in_add || d->C1 != 0 || d->out2 || d->gn_gamma) return 0;
     const int C = d->C0, hw = d->IH * d->IW;
@@ -347,8 +348,10 @@ extern "C" int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d) {
     return cpg % 8 == 0 && ((cpg / 8) & (cpg / 8 - 1)) == 0 && tpu * (cpg / 8) <= 64;
 }
 
-// Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
-extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
+// Whether the GroupNorm backward described by the gnb_* fields can run in the loader of this (data-gradient) launch.
+extern "C" int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d) { return small_gnb_fusable(d) || (d && ddpm_conv_img_fusable(d, 1)); }
+
+static int small_gn_fusable(const ddpm_conv_desc* d) {
     if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
     if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->res || d->act != 0 || d->sum_out) return 0;
     const int Cin = d->C0 + d->C1;
@@ -358,6 +361,9 @@ extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
     const int cpg = d->Cout / d->gn_groups;
     return cpg >= 4 && cpg <= 32 && 32 % cpg == 0;
 }
+
+// Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
+extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) { return small_gn_fusable(d) || (d && ddpm_conv_img_fusable(d, 0)); }
 
 // Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
 int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
@@ -375,12 +381,14 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps;
     a.gnb_raw = (const bf16*)d->gnb_raw; a.gnb_gamma = d->gnb_gamma; a.gnb_beta = d->gnb_beta; a.gnb_stats = d->gnb_stats;
     a.gnb_part = d->gnb_part; a.gnb_draw = (bf16*)d->gnb_draw; a.gnb_groups = d->gnb_groups; a.gnb_act = d->gnb_act;
-    if (d->gnb_raw && !(d->gnb_gamma && d->gnb_beta && d->gnb_stats && d->gnb_part && d->gnb_draw && ddpm_conv_gnb_fusable(d))) {
-        ddpm_set_error("conv: the fused GroupNorm backward needs all gnb_* pointers and a shape ddpm_conv_gnb_fusable() accepts");
+    if (d->gnb_raw && !small_gnb_fusable(d)) return 0;          // another kernel may take it (or the caller gets the error there)
+    if (d->gn_gamma && !small_gn_fusable(d)) return 0;
+    if (d->gnb_raw && !(d->gnb_gamma && d->gnb_beta && d->gnb_stats && d->gnb_part && d->gnb_draw)) {
+        ddpm_set_error("conv: the fused GroupNorm backward needs all gnb_* pointers");
         return -1;
     }
-    if (d->gn_gamma && !(d->gn_beta && d->gn_out && ddpm_conv_gn_fusable(d))) {
-        ddpm_set_error("conv: the fused GroupNorm needs gamma, beta, an output and a shape ddpm_conv_gn_fusable() accepts");
+    if (d->gn_gamma && !(d->gn_beta && d->gn_out)) {
+        ddpm_set_error("conv: the fused GroupNorm needs gamma, beta and an output");
         return -1;
     }
     const int tile_rows = d->IW == 8 ? 64 : 32;        // whole images: 8 of 2x2, 2 of 4x4, 1 of 8x8

@@ -400,11 +400,11 @@ class UNetEngine:
                 wd = wc.dgrad[name]
                 c0 = x0.v.shape[3]
                 dk = pack.DGRAD_KIND[kind]
-                if (norm and out_mask is None and x0.need_grad and dk == K33
+                if (norm and out_mask is None and x0.need_grad
                         and ops.conv_gnb_fusable(dk, dy, c0, groups, masked=in_mask is not None)):
-                    # low-resolution stages: the GroupNorm / activation backward runs in the loader of the data-gradient
-                    # convolution (its tile holds whole images and all channels), which also writes the raw gradient the
-                    # weight-gradient launch reads later
+                    # the GroupNorm / activation backward runs in the loader of the data-gradient convolution (its tile
+                    # holds whole images and whole groups), which also writes the raw gradient the weight-gradient launch
+                    # reads later
                     draw = torch.empty_like(raw)
                     dsum = self._take_zeros(n * c0, dev).view(n, c0) if in_add is not None else None
                     x0.g = ops.conv_forward(dk, dy, wd, None, c0, res=x0.g, rows=c0, sum_out=dsum,

@@ -118,7 +118,7 @@ def conv_gn_fusable(kind: int, x0: Tensor, x1: Optional[Tensor], cout: int, grou
     """Whether conv_forward(..., gn=...) is available for this convolution (no masks, no conv-side activation / residual)."""
     n, ih, iw, c0 = x0.shape
     d = hip.ConvDesc(kind=kind, N=n, IH=ih, IW=iw, C0=c0, C1=0 if x1 is None else x1.shape[3], Cout=cout, out_cs=cout,
-                     out_mode=hip.OUT_BF16_NHWC, gn_groups=groups)
+                     CoutW=(cout + 31) // 32 * 32, w_rows=(cout + 31) // 32 * 32, out_mode=hip.OUT_BF16_NHWC, gn_groups=groups)
     return bool(hip.lib().ddpm_conv_gn_fusable(C.byref(d)))
 
 

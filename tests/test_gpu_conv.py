@@ -169,7 +169,7 @@ def test_conv_with_fused_groupnorm(dev, n, ci, c1, co, hw, groups, act, with_res
     assert torch.equal(raw, raw2)
     torch.testing.assert_close(stats, stats2, rtol=1e-4, atol=1e-5)
     assert_rel(y.float().cpu(), y2.float().cpu(), 1e-2)
-    assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, nhwc(r16(hash_normal((2, 32, 16, 16), 69)), dev), None, 32, 16)   # image larger than a tile
+    assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, torch.empty(2, 64, 64, 32, device=dev, dtype=torch.bfloat16), None, 32, 16)   # image larger than a tile
 
 
 @pytest.mark.parametrize("n,c_used,co,h,wd,act", [(3, 1, 32, 32, 32, "gelu"), (2, 3, 32, 20, 72, "none"), (1, 3, 32, 64, 64, "silu"), (2, 4, 24, 8, 8, "none")])
@@ -237,7 +237,7 @@ def test_conv_dgrad_with_fused_groupnorm_backward(dev, n, c, c0, hw, groups, act
     assert_rel(dx1.float().cpu(), dx0.float().cpu())
     torch.testing.assert_close(part1.cpu(), part0.cpu(), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(dsum1.cpu(), dsum0.cpu(), rtol=1e-2, atol=2e-2)
-    assert not ops.conv_gnb_fusable(hip.CONV_3X3_S1, torch.empty(2, 16, 16, 32, device=dev, dtype=torch.bfloat16), 32, 16)
+    assert not ops.conv_gnb_fusable(hip.CONV_3X3_S1, torch.empty(2, 64, 64, 32, device=dev, dtype=torch.bfloat16), 32, 16)
 
 
 def _fwd_dgrad_check(dev, kind, n, ci, co, h, w_, seed=0):
@@ -318,3 +318,107 @@ def test_conv_large_launches_pick_the_wide_tiles(dev, want, kind, n, ci, co, h):
     torch like every other shape."""
     tf, _ = _fwd_dgrad_check(dev, kind, n, ci, co, h, h, seed=40)
     assert tf == want, (tf, want)
+
+
+# ---- whole-image tiles: conv -> GroupNorm -> act in one launch for every convolution kind of the Down / Up blocks
+IMG_FWD_CASES = [
+    # kind, N, Cin, C1 (concatenated), Cout, H (input), groups, act, residual, time-embedding add
+    (hip.CONV_3X3_S2, 3, 32, 0, 32, 32, 16, "gelu", False, True),       # encoder stage 0 entry at 32x32 input
+    (hip.CONV_3X3_S1, 2, 32, 0, 32, 16, 16, "gelu", True, False),
+    (hip.CONV_3X3_S1, 3, 32, 32, 32, 16, 16, "silu", False, True),      # decoder entry: concatenated skip connection
+    (hip.CONV_3X3_S2, 3, 32, 0, 64, 16, 16, "gelu", False, True),
+    (hip.CONV_3X3_S2, 5, 64, 0, 128, 8, 16, "gelu", False, True),       # two images per 32-row block, ragged batch
+    (hip.CONV_3X3_S2, 9, 128, 0, 256, 4, 16, "relu", False, True),      # eight images per block, ragged batch
+    (hip.CONVT_2X2_S2, 9, 256, 0, 128, 2, 16, "gelu", False, False),
+    (hip.CONVT_2X2_S2, 3, 128, 0, 64, 4, 16, "silu", False, False),
+    (hip.CONVT_2X2_S2, 2, 64, 0, 32, 8, 16, "gelu", False, False),
+    (hip.CONVT_2X2_S2, 2, 32, 0, 32, 16, 16, "gelu", False, False),     # 32x32 output: 1024 rows per image
+    (hip.CONV_3X3_S1, 2, 32, 0, 32, 32, 16, "gelu", False, False),      # the 32x32 stage of a 64x64 input
+    (hip.CONV_3X3_S2, 2, 32, 0, 64, 32, 16, "gelu", False, True),
+]
+
+
+@pytest.mark.parametrize("kind,n,ci,c1,co,h,groups,act,with_res,with_add", IMG_FWD_CASES)
+def test_conv_img_fused_groupnorm_forward(dev, kind, n, ci, c1, co, h, groups, act, with_res, with_add):
+    """conv -> GroupNorm -> act (+ residual) in one launch on whole-image tiles: raw result, statistics and normalised
+    output against torch fp32 on the same bf16 operands (1e-2 / 1.5e-2 of the scale; statistics 2e-2 / 1e-2 relative),
+    and against the two-launch path."""
+    from oracle import ref_cpu as O
+    k = 2 if kind == hip.CONVT_2X2_S2 else 3
+    x = r16(hash_normal((n, ci, h, h), 161))
+    xb = r16(hash_normal((n, c1, h, h), 162)) if c1 else None
+    wshape = (ci + c1, co, k, k) if kind == hip.CONVT_2X2_S2 else (co, ci + c1, k, k)
+    w = r16(hash_normal(wshape, 163) * (1.5 / (k * (ci + c1) ** 0.5)))
+    b = hash_normal((co,), 164) * 0.1
+    gamma, beta = 1 + 0.3 * hash_normal((co,), 165), 0.3 * hash_normal((co,), 166)
+    add = hash_normal((n, ci), 168) * 0.5 if with_add else None
+    xin = x if add is None else r16(x + add[:, :, None, None])
+    raw_ref = r16(torch_ref(kind, xin if xb is None else torch.cat([xin, xb], 1), w, b))
+    oh = raw_ref.shape[2]
+    res = r16(hash_normal((n, co, oh, oh), 167)) if with_res else None
+    y_ref = O.act_fn(act)(F.group_norm(raw_ref, groups, gamma, beta, eps=1e-5))
+    if with_res:
+        y_ref = y_ref + res
+    g = raw_ref.reshape(n, groups, -1)
+    mean_ref, rstd_ref = g.mean(2), (g.var(2, unbiased=False) + 1e-5).rsqrt()
+    x0d, x1d = nhwc(x, dev), (nhwc(xb, dev) if xb is not None else None)
+    wp = pack.pack_fwd(kind, w).to(dev)
+    assert ops.conv_gn_fusable(kind, x0d, x1d, co, groups)
+    kw = dict(x1=x1d, in_add=None if add is None else add.to(dev))
+    raw, y, stats = ops.conv_forward(kind, x0d, wp, b.to(dev), co, gn=(gamma.to(dev), beta.to(dev), groups, hip.ACT[act],
+                                                                       None if res is None else nhwc(res, dev)), **kw)
+    assert_rel(nchw(raw), raw_ref)
+    assert_rel(nchw(y), y_ref, 1.5e-2)
+    torch.testing.assert_close(stats[..., 0].cpu(), mean_ref, rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(stats[..., 1].cpu(), rstd_ref, rtol=1e-2, atol=1e-3)
+    raw2 = ops.conv_forward(kind, x0d, wp, b.to(dev), co, **kw)
+    y2, stats2 = ops.gn_act_forward(raw2, gamma.to(dev), beta.to(dev), groups, hip.ACT[act], res=None if res is None else nhwc(res, dev))
+    assert_rel(raw.float().cpu(), raw2.float().cpu(), 4e-3)              # other summation order: at most one bf16 step
+    torch.testing.assert_close(stats, stats2, rtol=2e-3, atol=2e-3)
+    assert_rel(y.float().cpu(), y2.float().cpu(), 1.5e-2)
+
+
+IMG_BWD_CASES = [
+    # forward kind of the unit, N, unit input channels (data-gradient width), unit output channels, H of the unit's OUTPUT, groups, act
+    (hip.CONV_3X3_S1, 2, 32, 32, 16, 16, "gelu"),
+    (hip.CONV_3X3_S1, 2, 32, 32, 32, 16, "gelu"),
+    (hip.CONV_3X3_S2, 2, 32, 32, 16, 16, "gelu"),       # dY 16x16 -> dX 32x32: four parity classes, 1024 rows per image
+    (hip.CONV_3X3_S2, 3, 32, 64, 8, 16, "silu"),
+    (hip.CONV_3X3_S2, 5, 64, 128, 4, 16, "gelu"),
+    (hip.CONVT_2X2_S2, 9, 256, 128, 4, 16, "gelu"),     # dY 4x4 -> dX 2x2: eight images per block, ragged batch
+    (hip.CONVT_2X2_S2, 3, 128, 64, 8, 16, "relu"),
+    (hip.CONVT_2X2_S2, 2, 64, 32, 16, 16, "gelu"),
+    (hip.CONVT_2X2_S2, 2, 32, 32, 32, 16, "gelu"),      # dY 32x32: the loader walks 64 chunks per image
+]
+
+
+@pytest.mark.parametrize("kind,n,c0,c,hw,groups,act", IMG_BWD_CASES)
+def test_conv_img_dgrad_with_fused_groupnorm_backward(dev, kind, n, c0, c, hw, groups, act):
+    """Data-gradient launch whose loader applies the unit's GroupNorm + activation backward, for every convolution kind: raw
+    gradient, per-image parameter-gradient rows, data-gradient and its per-image sums against the two-launch path (same
+    arithmetic, other summation order): 1e-2 of the scale for bf16 tensors, 2e-3 for the fp32 rows."""
+    k = 2 if kind == hip.CONVT_2X2_S2 else 3
+    dk = pack.DGRAD_KIND[kind]
+    raw = r16(hash_normal((n, hw, hw, c), 201) * 1.3 + 0.1).to(dev).bfloat16()
+    dy = r16(hash_normal((n, hw, hw, c), 202)).to(dev).bfloat16()
+    gamma, beta = (1 + 0.3 * hash_normal((c,), 203)).to(dev), (0.3 * hash_normal((c,), 204)).to(dev)
+    wshape = (c0, c, k, k) if kind == hip.CONVT_2X2_S2 else (c, c0, k, k)
+    w = r16(hash_normal(wshape, 205) * (1.0 / (k * c ** 0.5)))
+    wd = pack.pack_dgrad(kind, w).to(dev)
+    ih = {hip.CONV_3X3_S1: hw, hip.CONV_3X3_S2: 2 * hw, hip.CONVT_2X2_S2: hw // 2}[kind]
+    res = r16(hash_normal((n, ih, ih, c0), 206)).to(dev).bfloat16()
+    _, stats = ops.gn_act_forward(raw, gamma, beta, groups, hip.ACT[act])
+    part0 = torch.zeros(n, 3, c, device=dev)
+    draw0 = ops.gn_act_backward(raw, dy, gamma, beta, groups, hip.ACT[act], stats, part0)
+    dsum0 = torch.zeros(n, c0, device=dev)
+    dx0 = ops.conv_forward(dk, draw0, wd, None, c0, res=res, rows=c0, sum_out=dsum0)
+    assert ops.conv_gnb_fusable(dk, dy, c0, groups)
+    part1 = torch.full((n, 3, c), float("nan"), device=dev)
+    draw1 = torch.full_like(raw, float("nan"))
+    dsum1 = torch.zeros(n, c0, device=dev)
+    dx1 = ops.conv_forward(dk, dy, wd, None, c0, res=res, rows=c0, sum_out=dsum1,
+                           gnb=(raw, gamma, beta, groups, hip.ACT[act], stats, part1, draw1))
+    assert_rel(draw1.float().cpu(), draw0.float().cpu())
+    assert_rel(dx1.float().cpu(), dx0.float().cpu())
+    torch.testing.assert_close(part1.cpu(), part0.cpu(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(dsum1.cpu(), dsum0.cpu(), rtol=1e-2, atol=2e-2 * max(1.0, hw / 8))
