@@ -310,11 +310,13 @@ __device__ __forceinline__ void img_stage_gnb(const ImgArgs& a, char* s_patch, f
 template <int WM, int WN, int MT, int NT, int T, int MODE>
 __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
     constexpr int ROWS = WM * MT * 32, BN = WN * NT * 32;
-    static_assert(T >= WM * WN * 64, "more tiles than waves");
+    static_assert(T >= WM * WN * 64 && T % (BN / 8) == 0, "more tiles than waves");
     constexpr int OS = BN * 2 + 16;        // result tile row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ImgGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler must know it: everything
+                                                                  // derived from it (class, tap range, loop bounds) stays scalar
     const bool mm = wid < WM * WN;              // waves beyond the tile grid only help the loader and the epilogue
     const int wm = mm ? wid % WM : 0, wn = mm ? wid / WM : 0;
     const int n0 = blockIdx.x * g.NB, co0 = blockIdx.y * BN;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
     }
     __syncthreads();
 
-    // ---- weight rows of this tile's output channels, every tap: [tap][BN][Cin] -> LDS
-    {
+    // ---- staging: weight rows of this tile's output channels for every tap ([tap][BN][Cin]) and the input patches -> LDS
+    if (MODE == IMG_BWD_GN) {
         const int vpr = a.Cin >> 3;
         const int items = a.ntaps * BN << a.vpr_shift;
 #pragma unroll 8
@@ -341,15 +343,53 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
             const bf16x8 v = *(const bf16x8*)(a.w + ((long long)s_tab[TAB_SLICE + j] * a.w_rows + co0 + c) * a.Cin + vec * 8);
             *(bf16x8*)(s_w + row * a.WS + vec * 16) = v;
         }
-    }
-    IMG_STAMP(1);
-    if (MODE == IMG_BWD_GN) {
+        IMG_STAMP(1);
         float* s_red = (float*)(smem + a.red_off);
         if (a.gnb_act == ACT_GELU) img_stage_gnb<T, ACT_GELU>(a, s_patch, s_red, n0, tid, blockIdx.y == 0);
         else if (a.gnb_act == ACT_SILU) img_stage_gnb<T, ACT_SILU>(a, s_patch, s_red, n0, tid, blockIdx.y == 0);
         else img_stage_gnb<T, -1>(a, s_patch, s_red, n0, tid, blockIdx.y == 0);
     } else {
-        img_stage_plain<T>(a, s_patch, n0, tid);
+        // one item space (patch vectors first, weight vectors after them), walked eight items per thread at a time so that
+        // the loads of both kinds are in flight together: one round trip to memory instead of two
+        const int vpr = a.Cin >> 3, php = g.PH * g.PW;
+        const int n_patch = g.NB * php << a.vpr_shift;
+        const int items = n_patch + (a.ntaps * BN << a.vpr_shift);
+#pragma unroll 8
+        for (int idx = tid; idx < items; idx += T) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+            int dst;
+            if (idx < n_patch) {
+                const int pix = idx >> a.vpr_shift, vec = idx & (vpr - 1);
+                const int il = div_fast(pix, g.phw_magic), r = pix - il * php;
+                const int py = div_fast(r, g.pw_magic), px = r - py * g.PW;
+                const int n = n0 + il, iy = py + g.dmin_h, ix = px + g.dmin_w;
+                dst = pix * a.AS + vec * 16;
+                if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                    const long long p = ((long long)n * g.IH + iy) * g.IW + ix;
+                    const int c = vec * 8;
+                    if (c < a.C0) {
+                        v = *(const bf16x8*)(a.in0 + p * a.C0 + c);
+                        if (a.in_add) {
+                            const float* ad = a.in_add + (long long)n * a.C0 + c;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + ad[j]);
+                        }
+                    } else {
+                        v = *(const bf16x8*)(a.in1 + p * a.C1 + (c - a.C0));
+                    }
+                }
+            } else {
+                const int wi = idx - n_patch;
+                const int row = wi >> a.vpr_shift, vec = wi & (vpr - 1);
+                const int j = row / BN, c = row - j * BN;
+                v = *(const bf16x8*)(a.w + ((long long)s_tab[TAB_SLICE + j] * a.w_rows + co0 + c) * a.Cin + vec * 8);
+                dst = a.w_off + row * a.WS + vec * 16;
+            }
+            *(bf16x8*)(smem + dst) = v;
+        }
+        IMG_STAMP(1);
     }
     IMG_STAMP(2);
 
@@ -378,41 +418,62 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     }
+    // the epilogue's per-channel operands: a thread's 8-channel vector is the same for all its result vectors (T is a multiple
+    // of BN / 8), so they are fetched here, where the latency hides behind the matrix work
+    const int my_part = tid % (BN / 8);
+    f32x4 gm0, gm1, bt0, bt1;
+    if (MODE == IMG_FWD_GN) {
+        const int co = co0 + my_part * 8;
+        gm0 = *(const f32x4*)(a.gn_gamma + co); gm1 = *(const f32x4*)(a.gn_gamma + co + 4);
+        bt0 = *(const f32x4*)(a.gn_beta + co); bt1 = *(const f32x4*)(a.gn_beta + co + 4);
+    }
     __syncthreads();
     IMG_STAMP(3);
 
-    // ---- MFMA over taps x k-steps of 16 channels; operand fragments of step s + D are requested while step s computes
+    // ---- MFMA over taps x k-steps of 16 channels; the operand fragments of step s + D are requested right after step s has
+    //      been issued (steady-state loop without conditions, so that the waits count exactly; the last 2 D - 1 steps peeled)
     if (mm) {
         constexpr int D = MT * NT >= 4 ? 2 : 4;
         const int ks_shift = a.vpr_shift - 1, ksteps = 1 << ks_shift;       // Cin / 16
         const int total = ntaps << ks_shift;
+        const int tap_stride = BN * a.WS;
         bf16x8 fa[D][MT], fb[D][NT];
         auto fetch = [&](int st, bf16x8 (&av)[MT], bf16x8 (&bv)[NT]) {
             const int j = st >> ks_shift, kk = st & (ksteps - 1);
             const int poff = __builtin_amdgcn_readlane(my_poff, j);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = *(const bf16x8*)(s_patch + a_base[mt] + poff + kk * 32);
-            const char* bp = s_w + (tap0 + j) * BN * a.WS + b_base + kk * 32;
+            const char* bp = s_w + (tap0 + j) * tap_stride + b_base + kk * 32;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const bf16x8*)(bp + nt * 32 * a.WS);
+        };
+        auto step = [&](bf16x8 (&av)[MT], bf16x8 (&bv)[NT]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
         };
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (d < total) fetch(d, fa[d], fb[d]);
-        for (int s0 = 0; s0 < total; s0 += D) {
+        int st = 0;
+        for (; st + 2 * D <= total; st += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const int st = s0 + d;
-                if (st < total) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][mt], fb[d][nt], acc[mt][nt], 0, 0, 0);
-                    if (st + D < total) fetch(st + D, fa[d], fb[d]);
-                }
+                step(fa[d], fb[d]);
+                fetch(st + D + d, fa[d], fb[d]);
             }
         }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (st + d < total) {
+                step(fa[d], fb[d]);
+                if (st + D + d < total) fetch(st + D + d, fa[d], fb[d]);
+            }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (st + D + d < total) step(fa[d], fb[d]);
     }
 
     IMG_STAMP(4);
@@ -443,7 +504,9 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
     // ---- result tile -> LDS (bf16)
     __syncthreads();                       // every wave is done with the operand tiles
     char* s_out = smem;
-    float* s_st = (float*)(smem + ROWS * OS);
+    float* s_st = (float*)(smem + ROWS * OS);     // [images of the tile][groups of the tile][2] mean, rstd
+    float* s_stp = s_st + 2 * BN;                 // one image per tile: [WM][groups of the tile][2] per-wave sums
+    const bool reg_stats = MODE == IMG_FWD_GN && g.NB == 1;
     if (mm) {
         if (MODE != IMG_FWD_GN && a.act) { // rare: a convolution-side activation (the units this kernel serves have none)
 #pragma unroll
@@ -453,6 +516,9 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
 #pragma unroll 1
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_fwd(acc[mt][nt][r] + bias_r[nt], a.act) - bias_r[nt];
         }
+        float st1[NT], st2[NT];                    // this lane's column sums over its rows, of the bf16 values
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) st1[nt] = st2[nt] = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -461,9 +527,27 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (rb0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    *(bf16*)(s_out + row * OS + col * 2) = (bf16)(acc[mt][nt][r] + bias_r[nt]);
+                    const bf16 hv = (bf16)(acc[mt][nt][r] + bias_r[nt]);
+                    *(bf16*)(s_out + row * OS + col * 2) = hv;
+                    if (MODE == IMG_FWD_GN) { const float f = (float)hv; st1[nt] += f; st2[nt] += f * f; }
                 }
             }
+        if (reg_stats) {
+            // one image per tile: every row of the tile belongs to it, so the statistics come straight from the registers:
+            // lanes of a group (and the two row halves of the wave) -> per-wave sums -> added over the row waves below
+            const int cpg_ = 1 << a.gn_cpg_shift;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float u = st1[nt], v = st2[nt];
+                u += __shfl_xor(u, 32, 64); v += __shfl_xor(v, 32, 64);
+                for (int o = 1; o < cpg_; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+                if (lane < 32 && (lane & (cpg_ - 1)) == 0) {
+                    const int grp = (wn * NT * 32 + nt * 32 + lane) >> a.gn_cpg_shift;
+                    s_stp[(wm * (BN >> a.gn_cpg_shift) + grp) * 2] = u;
+                    s_stp[(wm * (BN >> a.gn_cpg_shift) + grp) * 2 + 1] = v;
+                }
+            }
+        }
     }
     __syncthreads();
     IMG_STAMP(5);
@@ -474,6 +558,22 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
         // ---- statistics per (image of the tile, group of the tile) over the bf16 values of every class
         cpg = 1 << a.gn_cpg_shift; gpt = BN >> a.gn_cpg_shift;
         const int gpt_shift = __builtin_ctz(BN) - a.gn_cpg_shift;
+        if (reg_stats) {
+            if (tid < gpt) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { s1 += s_stp[(w * gpt + tid) * 2]; s2 += s_stp[(w * gpt + tid) * 2 + 1]; }
+                const float m = 1.0f / (float)((g.ncls << a.p_shift) * cpg);
+                const float mean = s1 * m;
+                const float rstd = rsqrtf(fmaxf(s2 * m - mean * mean, 0.f) + a.gn_eps);
+                s_st[tid * 2] = mean; s_st[tid * 2 + 1] = rstd;
+                if (n0 < g.N && a.gn_stats) {
+                    const int gi = (co0 >> a.gn_cpg_shift) + tid;
+                    a.gn_stats[((long long)n0 * a.gn_groups + gi) * 2] = mean;
+                    a.gn_stats[((long long)n0 * a.gn_groups + gi) * 2 + 1] = rstd;
+                }
+            }
+        } else {
         const int npairs = g.NB * gpt;
         int tpp = T / npairs;                                  // threads per pair: a power of two, at most one wave
         if (tpp > 64) tpp = 64;
@@ -518,6 +618,7 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
                 }
             }
         }
+        }
         __syncthreads();
     }
 
@@ -552,8 +653,7 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
         }
         if (MODE == IMG_FWD_GN) {
             const long long e = pixel * a.Cout + co;
-            const f32x4 g0 = *(const f32x4*)(a.gn_gamma + co), g1 = *(const f32x4*)(a.gn_gamma + co + 4);
-            const f32x4 b0 = *(const f32x4*)(a.gn_beta + co), b1 = *(const f32x4*)(a.gn_beta + co + 4);
+            const f32x4 g0 = gm0, g1 = gm1, b0 = bt0, b1 = bt1;       // part == my_part
             bf16x8 rv;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rv[j] = (bf16)0.f;
@@ -649,7 +749,7 @@ static bool img_plan(const ddpm_conv_desc* d, ImgPlan* p) {
         (void)threads;
         const size_t red = d->gnb_groups > 0 ? (size_t)(NB * d->gnb_groups * 4 + NB * Cin * 2 + (gnb_items / 64 > 8 ? gnb_items / 64 : 8) * Cin * 2) * 4 : 0;
         const size_t stage = patch + wbytes + red;
-        const size_t outb = (size_t)rows * (c * 2 + 16) + (size_t)NB * c * 2 * 4 + 64;
+        const size_t outb = (size_t)rows * (c * 2 + 16) + (size_t)(NB > 1 ? NB : 2) * c * 2 * 4 + (size_t)16 * c * 8 + 64;
         const size_t body = ((stage > outb ? stage : outb) + 15) / 16 * 16;
         const size_t need = body + TAB_INTS * 4;
         if (need > 160 * 1024) continue;
