@@ -65,19 +65,106 @@ def cpu_baseline(channels, size, batch, steps):
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
-    # sampling: a few steps of the ancestral chain, extrapolated to the full T = 120 steps
+    # sampling: a few timed steps of the ancestral chain (extrapolated to T = 120), then one full chain
     with torch.no_grad():
         frozen = {k: v.detach() for k, v in p.items()}
         x = torch.randn(batch, channels, size, size)
-        ssteps = 4
-        xs = O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x) for _ in range(ssteps)], steps=1)
+        ssteps = 3
+        O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x)], steps=1)
         t1 = time.perf_counter()
-        xs = O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x) for _ in range(ssteps)], steps=ssteps)
+        O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x) for _ in range(ssteps)], steps=ssteps)
         ds = (time.perf_counter() - t1) / ssteps
+        t1 = time.perf_counter()
+        O.sample_chain(frozen, cfg, s, x, 120, [torch.randn_like(x) for _ in range(120)])
+        dfull = time.perf_counter() - t1
     return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of batch {batch} at {size}x{size}x{channels} (oracle/ref_cpu.py, fp32, dropout on, Adam)",
-            "sampling": {"value": batch / (120 * ds), "unit": "images/s",
-                         "sample": f"{ssteps} sampling steps of batch {batch}, extrapolated to the 120-step chain"}}
+            "sample": f"{steps} train steps of batch {batch} at {size}x{size}x{channels} (oracle/ref_cpu.py, fp32, dropout on, Adam; "
+                      "the reference trainer's per-iteration checkpoint, EMA and sleeps excluded)",
+            "sampling": {"value": batch / dfull, "unit": "images/s", "sample": f"one full 120-step chain of batch {batch}",
+                         "extrapolated_from_3_steps": batch / (120 * ds)}}
+
+
+def dropin_eager(dev, channels, size, batch, micro_steps=9):
+    """The reference trainer's own loop shape through the drop-in modules, no graph driver (base_trainer.py:196-235 there):
+    randint -> q -> model -> criterion -> loss.backward(retain_graph=True) -> optimizer.step() + zero_grad on every 3rd
+    micro-batch (gradient accumulation 3, no 1/3 scaling)."""
+    m = build_model(dev, channels)
+    m.train()
+    crit = ELBOLoss("mse")
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    x0 = torch.rand(batch, channels, size, size, device=dev) * 2 - 1
+
+    def micro(i):
+        t = torch.randint(1, m.T + 1, (batch,), device=dev)
+        x_t = m.q(x0, t)
+        loss = crit(m, t, m(x_t, t), x0, is_ddp=False)["Loss"]
+        loss.backward(retain_graph=True)
+        if i % 3 == 0:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+
+    for i in range(1, 4):
+        micro(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1, micro_steps + 1):
+        micro(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / micro_steps
+    return {"value": batch / dt, "unit": "images/s", "ms_per_micro_step": 1e3 * dt, "gradient_accumulation_steps": 3,
+            "what": "the reference trainer's loop (randint, q, model, criterion, backward(retain_graph), step every 3rd) on the module "
+                    "surface without a graph driver: host-launch bound"}
+
+
+def timed(step_fn, steps, warmup, barrier, dist, dev):
+    for _ in range(warmup):
+        step_fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        import torch.distributed as td
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = tt.item()
+    return dt
+
+
+def extra_configs(dev, world, dist, barrier, reducer_factory, use_graph):
+    """The other GPU configs BASELINE.json names, same code, shorter runs: Flowers102-shaped 64x64x3 training (batch 128 per
+    GPU, data parallel when N > 1) and 128x128x3 sampling with self-attention at the 16x16 stage (128 images per GPU)."""
+    out = {}
+    # -- 64x64x3 training
+    m = build_model(dev, 3)
+    m.train()
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    b = 128
+    x0 = torch.rand(b, 3, 64, 64, device=dev) * 2 - 1
+    red = reducer_factory(m) if dist else None
+    step = graphs.PipelinedTrainStep(m, ELBOLoss("mse"), opt, x0, red, use_graph=use_graph)
+    dt = timed(step.replay, 20, 5, barrier, dist, dev)
+    out["train_64x64x3"] = {"value": b * world * 20 / dt, "unit": "images/s", "ms_per_step": 50 * dt, "batch_per_gpu": b, "n_gpus": world,
+                            "workload": "DDPM train step, 64x64x3 (Flowers102-shaped), batch 128/GPU, drop_p=0.1, Adam"}
+    m.eval()
+    smp = graphs.GraphedSampler(m, 256, (64, 64), use_graph=use_graph)
+    dt = timed(smp.sample, 1, 1, barrier, dist, dev)
+    out["sample_64x64x3"] = {"value": 256 * world / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / 120, "batch_per_gpu": 256, "n_gpus": world,
+                             "workload": "DDPM full T=120 ancestral sampling, 64x64x3, 256 images/GPU"}
+    del step, smp, m, opt
+    torch.cuda.empty_cache()
+    # -- 128x128x3 sampling with attention at the 16x16 stage
+    m = build_model(dev, 3, [2])
+    m.eval()
+    nb = 128
+    smp = graphs.GraphedSampler(m, nb, (128, 128), use_graph=use_graph)
+    dt = timed(smp.sample, 1, 1, barrier, dist, dev)
+    out["sample_128x128x3_attention"] = {"value": nb * world / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / 120, "batch_per_gpu": nb,
+                                         "n_gpus": world, "workload": "DDPM full T=120 ancestral sampling, 128x128x3, self-attention at the "
+                                                                      "16x16 stage (C=128, 256 tokens, 8 heads), 128 images/GPU"}
+    return out
 
 
 def launch_ranks(n: int, argv) -> int:
@@ -134,6 +221,8 @@ def main():
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (64x64x3 training, 128x128x3 sampling), the "
+                                                            "gradient-accumulation-3 step and the eager drop-in loop")
     ap.add_argument("--detail", default="", help="write a per-launch-shape timing table of the roofline pass to this file")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check: every rank prints its rendezvous environment and exits (no GPU work)")
     a = ap.parse_args()
@@ -230,13 +319,14 @@ def main():
         m.eval()
         nb = a.sample_batch
         if a.sample_streams > 1:
-            sampler = graphs.ConcurrentSampler(m, nb // a.sample_streams, (a.size, a.size), a.sample_streams, use_graph=not a.no_graph)
+            sampler = graphs.ConcurrentSampler(m, nb // a.sample_streams, (a.size, a.size), a.sample_streams, use_graph=not a.no_graph,
+                                               first_image=rank * nb, seed=20240229)
         else:
-            sampler = graphs.GraphedSampler(m, nb, (a.size, a.size), use_graph=not a.no_graph)
+            sampler = graphs.GraphedSampler(m, nb, (a.size, a.size), use_graph=not a.no_graph, first_image=rank * nb, seed=20240229)
         if dist:
             # the job's images: every rank runs its own chains, one gather to rank 0 at the end of each job
             from dm_amd.runtime.dp import sample_sharded
-            run_chain = lambda: sample_sharded(lambda n: sampler.sample(), nb * world)      # noqa: E731
+            run_chain = lambda: sample_sharded(lambda n, first: sampler.sample(), nb * world)      # noqa: E731
         else:
             run_chain = sampler.sample
         run_chain()
@@ -270,8 +360,32 @@ def main():
             with open(a.detail, "w") as f:
                 for k, cnt, us, gbs, tf in sorted(rows, key=lambda r: -r[1] * r[2]):
                     f.write(f"{k:60s} x{cnt:3d} {us:8.1f} us {gbs:8.1f} GB/s {tf:7.1f} TF/s  {cnt * us:8.1f} us/step\n")
+    if not a.no_extra:
+        del step
+        torch.cuda.empty_cache()
+        if not dist:
+            # the reference trainer's default: gradients of 3 micro-batches summed, optimizer step on the 3rd (Q8)
+            m3 = build_model(dev, a.channels)
+            m3.train()
+            s3 = graphs.PipelinedTrainStep(m3, crit, FusedAdam(m3.parameters(), lr=1e-3), x0, None, phases=a.phases, use_graph=not a.no_graph,
+                                           gradient_accumulation_steps=3)
+            dt3 = timed(s3.replay, 30, 6, barrier, dist, dev)
+            out["gradient_accumulation_3"] = {"value": a.batch * 30 / dt3, "unit": "images/s", "ms_per_micro_step": 1e3 * dt3 / 30,
+                                              "what": "same workload, optimizer step on every 3rd micro-batch (the reference trainer's default)"}
+            del s3, m3
+            torch.cuda.empty_cache()
+            out["dropin_eager"] = dropin_eager(dev, a.channels, a.size, a.batch)
+        if dist:
+            from dm_amd.runtime.dp import GradReducer
+            def rf(mm):
+                r_ = GradReducer(list(mm.parameters()), 2 if rehearse else world, bucket_bytes=a.bucket_mb << 20)
+                r_.broadcast_parameters()
+                return r_
+        else:
+            rf = None
+        out["extra_configs"] = extra_configs(dev, world, dist, barrier, rf, not a.no_graph)
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(a.channels, a.size, 64, 3)
+        out["cpu_baseline"] = cpu_baseline(a.channels, a.size, 64, 10)
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -19,6 +19,8 @@
 #include "conv_geom.h"
 #include "ddpm_hip.h"
 
+#include <stdlib.h>
+
 // Diagnostic build only (-DIMG_STAMPS): lane 0 of wave 0 of every workgroup records the constant-rate clock at phase boundaries.
 #ifdef IMG_STAMPS
 __device__ unsigned long long* img_dbg = nullptr;
@@ -699,7 +701,8 @@ static bool img_layout(int rows, int bn, int* wm, int* wn, int* mt, int* nt) {
 
 // Fills the plan when this kernel can run the problem (fused GroupNorm forward or backward form included); false otherwise.
 static bool img_plan(const ddpm_conv_desc* d, ImgPlan* p) {
-    if (!d) return false;
+    static const bool off = getenv("DDPM_NO_CONV_IMG") != nullptr;      // measurement switch: everything falls back to the other kernels
+    if (!d || off) return false;
     const int kind = d->kind;
     if (kind != CONV_3X3_S1 && kind != CONV_3X3_S2 && kind != CONVT_2X2_S2 && kind != DGRAD_3X3_S2 && kind != DGRAD_CONVT_2X2) return false;
     if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->out2 || d->C0_used) return false;

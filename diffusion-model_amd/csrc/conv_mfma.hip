@@ -326,7 +326,8 @@ static int launch_conv(const ConvArgs& a, size_t lds, hipStream_t stream) {
 
 // Test hook: the tile the next general-kernel launches of this thread must use (0 = choose by shape) and the tile the last
 // one used, both coded wm * 100 + wn * 10 + nt.
-static thread_local int g_force_tile = 0, g_last_tile = 0;
+static thread_local int g_force_tile = 0, g_last_tile = 0, g_last_kernel = 0;
+extern "C" int ddpm_conv_last_kernel(void) { return g_last_kernel; }
 extern "C" int ddpm_conv_debug_tile(int force) {
     const int last = g_last_tile;
     if (force >= 0) g_force_tile = force;
@@ -348,12 +349,12 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
     // 3x3 convolutions on 2x2 / 4x4 images (the deepest stages) have their own kernel
-    if (const int rc = ddpm_conv_small_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
+    if (const int rc = ddpm_conv_small_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_SMALL; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     // whole-image tiles: the unit's GroupNorm (forward) or its backward (data-gradient launches) runs in the same launch
-    if (const int rc = ddpm_conv_img_try(d, stream, 0)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
+    if (const int rc = ddpm_conv_img_try(d, stream, 0)) { g_last_kernel = DDPM_CONV_KERNEL_IMAGE; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     DDPM_REQUIRE(!d->gnb_raw, "conv: no fused GroupNorm backward for this shape (ask ddpm_conv_gnb_fusable first)");
     // the image head (a handful of output channels) runs on the vector ALUs
-    if (const int rc = ddpm_conv_thin_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
+    if (const int rc = ddpm_conv_thin_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_THIN; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     DDPM_REQUIRE(!d->gn_gamma, "conv: no fused GroupNorm for this shape (ask ddpm_conv_gn_fusable first)");
 
     ConvArgs a;
@@ -391,6 +392,7 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     const int npix = a.g.NB * a.g.PH * a.g.PW;
     const int bm = 32 * cfg.wm, bn = 32 * cfg.nt * cfg.wn;
     g_last_tile = cfg.wm * 100 + cfg.wn * 10 + cfg.nt;
+    g_last_kernel = DDPM_CONV_KERNEL_GENERAL;
     size_t lds = ((size_t)npix * 4 + 15) / 16 * 16 + CONV_MAX_TAPS * 4 + (size_t)npix * CONV_RS + (size_t)a.g.max_taps * bn * CONV_RS;
     const size_t lds_out = (size_t)bm * (bn * 2 + 16);
     if (lds < lds_out) lds = lds_out;

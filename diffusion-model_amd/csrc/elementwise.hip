@@ -33,7 +33,7 @@ int ddpm_check_launch(const char* what) {
 }
 
 extern "C" const char* ddpm_last_error(void) { return g_err; }
-extern "C" int ddpm_abi_version(void) { return 1; }
+extern "C" int ddpm_abi_version(void) { return 2; }
 
 static inline int stream_grid(long long work_items, int block) {
     long long g = (work_items + block - 1) / block;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restri
                                                             const long long* __restrict__ t, const float* __restrict__ noise,
                                                             const float* __restrict__ sched, float* __restrict__ out, int N, long long chw,
                                                             const unsigned long long* __restrict__ seed, unsigned stream_id,
-                                                            int sigmoid_pred) {
+                                                            int sigmoid_pred, unsigned long long q0) {
     const long long total4 = (long long)N * chw / 4;
     const unsigned long long sd = seed ? *seed : 0ull;
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < total4; q += (long long)gridDim.x * blockDim.x) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restri
         const float A = sched[ti * SC_STRIDE + SC_A], B = sched[ti * SC_STRIDE + SC_B], Cc = sched[ti * SC_STRIDE + SC_C];
         const f32x4 x = *(const f32x4*)(xt + e);
         f32x4 p = *(const f32x4*)(x0p + e);
-        const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, stream_id, (unsigned long long)q);
+        const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, stream_id, q0 + (unsigned long long)q);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -126,16 +126,35 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restri
 
 extern "C" int ddpm_reverse_step(const float* xt, const float* x0_pred, const int64_t* t_, const float* noise, const float* sched,
                                  float* out, int N, int64_t chw, const uint64_t* seed_, uint32_t stream_id, int sigmoid_pred,
-                                 ddpm_stream_t stream_) {
+                                 uint64_t first_index, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long* t = (const long long*)t_;
     const unsigned long long* seed = (const unsigned long long*)seed_;
     DDPM_REQUIRE(xt && x0_pred && t && sched && out, "reverse_step: null pointer");
     DDPM_REQUIRE(noise || seed, "reverse_step: need an external noise tensor or a device seed");
     DDPM_REQUIRE(N > 0 && chw > 0 && chw % 4 == 0, "reverse_step: C*H*W must be a positive multiple of 4 (got %lld)", chw);
+    DDPM_REQUIRE(first_index % 4 == 0, "reverse_step: first_index must be a multiple of 4");
     hipLaunchKernelGGL(reverse_step_kernel, dim3(stream_grid((long long)N * chw / 4, 256)), dim3(256), 0, stream, xt, x0_pred, t, noise,
-                       sched, out, N, chw, seed, stream_id, sigmoid_pred);
+                       sched, out, N, chw, seed, stream_id, sigmoid_pred, (unsigned long long)(first_index / 4));
     return ddpm_check_launch("reverse_step");
+}
+
+// out[i] = the N(0,1) sample of flat element first_index + i of stream `stream_id` of the (*seed) sequence: the start tensor
+// X_T of a sampling job (ddpm.py:152 of the reference: randn), keyed by GLOBAL element index so that a job sharded over
+// several GPUs draws the same numbers whatever the number of GPUs.
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, long long n4, const unsigned long long* __restrict__ seed,
+                                                           unsigned stream_id, unsigned long long q0) {
+    const unsigned long long sd = *seed;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x)
+        *(f32x4*)(out + q * 4) = philox_normal4(sd, stream_id, q0 + (unsigned long long)q);
+}
+
+extern "C" int ddpm_fill_normal(float* out, int64_t n, const uint64_t* seed, uint32_t stream_id, uint64_t first_index, ddpm_stream_t stream_) {
+    DDPM_REQUIRE(out && seed, "fill_normal: null pointer");
+    DDPM_REQUIRE(n > 0 && n % 4 == 0 && first_index % 4 == 0, "fill_normal: n and first_index must be multiples of 4");
+    hipLaunchKernelGGL(fill_normal_kernel, dim3(stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, out, (long long)(n / 4),
+                       (const unsigned long long*)seed, stream_id, (unsigned long long)(first_index / 4));
+    return ddpm_check_launch("fill_normal");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -128,10 +128,11 @@ class DDPM(nn.Module):
 
     @torch.no_grad()
     def reverse_q(self, x_t: Tensor, x0_predicted: Tensor, T: Tensor, noise: Optional[Tensor] = None,
-                  out: Optional[Tensor] = None, _sigmoid: bool = False, _seed: Optional[Tensor] = None) -> Tensor:
+                  out: Optional[Tensor] = None, _sigmoid: bool = False, _seed: Optional[Tensor] = None, _first_index: int = 0) -> Tensor:
         """x_{t-1} = A_t x_t + B_t x0_pred + C_t z (x0-form posterior).  z is drawn in-kernel (Philox) unless `noise` is
         given; _seed (a device int64 tensor, advanced by a kernel after use) replaces the module's own seed for callers
-        that run several chains at once."""
+        that run several chains at once; _first_index: global flat index of x_t's first element in a job sharded over GPUs
+        (the in-kernel noise is keyed by global element index)."""
         self._need_gpu(x_t, "reverse_q")
         x_t = x_t.float().contiguous()
         x0_predicted = x0_predicted.float().contiguous()
@@ -145,11 +146,11 @@ class DDPM(nn.Module):
         if noise is not None:
             noise = noise.float().contiguous()
             hip.call("ddpm_reverse_step", hip.ptr(x_t), hip.ptr(x0_predicted), hip.ptr(t), hip.ptr(noise), hip.ptr(tab), hip.ptr(out),
-                     n, chw, None, 0, int(_sigmoid), hip.stream())
+                     n, chw, None, 0, int(_sigmoid), 0, hip.stream())
         else:
             seed = _seed if _seed is not None else self._rng_seed(x_t.device)
             hip.call("ddpm_reverse_step", hip.ptr(x_t), hip.ptr(x0_predicted), hip.ptr(t), None, hip.ptr(tab), hip.ptr(out),
-                     n, chw, hip.ptr(seed), 2, int(_sigmoid), hip.stream())
+                     n, chw, hip.ptr(seed), 2, int(_sigmoid), int(_first_index), hip.stream())
             hip.call("ddpm_bump_seed", hip.ptr(seed), hip.stream())
         return out
 

@@ -130,14 +130,17 @@ def shard_range(total: int, rank: int, world: int):
 @torch.no_grad()
 def sample_sharded(sample_fn, total: int, group=None) -> Optional[Tensor]:
     """Ancestral sampling of `total` images over all ranks: the chains are independent, so rank r runs
-    sample_fn(n_r) -> [n_r, C, H, W] for its contiguous share (shard_range) with no inter-GPU traffic during the T
-    steps, and ONE gather at the end brings the images to rank 0 (returned there in global order; None elsewhere).
-    sample_fn is e.g. `lambda n: ddpm.sample_tensor(n, shape)` or a GraphedSampler's sample (the reference samples on
-    rank 0 only, base_trainer.py:146-147,337-349).  Ranks draw their noise from their own generators (seed + rank)."""
+    sample_fn(n_r, first_r) -> [n_r, C, H, W] for its contiguous share [first_r, first_r + n_r) (shard_range) with no
+    inter-GPU traffic during the T steps, and ONE gather at the end brings the images to rank 0 (returned there in global
+    order; None elsewhere).  The reference samples on rank 0 only (base_trainer.py:146-147,337-349).
+
+    sample_fn receives the global index of its first image so that it can key its noise by global image index: a
+    graphs.GraphedSampler built with `seed=job_seed, first_image=first_r` draws the same numbers for image i whatever the
+    number of ranks, which makes the gathered result independent of the world size."""
     world = td.get_world_size(group) if td.is_initialized() else 1
     rank = td.get_rank(group) if td.is_initialized() else 0
     b, e = shard_range(total, rank, world)
-    x = sample_fn(e - b) if e > b else None
+    x = sample_fn(e - b, b) if e > b else None
     if world == 1:
         return x
     # every rank must take part in the gather with equally shaped buffers: pad the shares to the largest one

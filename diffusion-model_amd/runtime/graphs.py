@@ -269,6 +269,13 @@ class PipelinedTrainStep:
                 self._handles.append(self.reducer.start_range(flat, *self._ranges[0]))
             self._handles.append(self.reducer.start_range(flat, *self._ranges[1]))
 
+    def _finish_exchange(self):
+        """wait for the started range exchanges in the order they were started (every rank starts them in the same order,
+        which is what a collective library requires)"""
+        for h in self._handles:
+            self.reducer.finish(h)
+        self._handles.clear()
+
     def _run(self, graphs, exchange: bool = True, last: bool = False):
         main = torch.cuda.current_stream()
         gm, gw, gc, gp = graphs if graphs is not None else (None, None, None, None)
@@ -318,9 +325,7 @@ class PipelinedTrainStep:
                     self._pre()
             return
         main.wait_stream(self.side)
-        for h in self._handles:
-            self.reducer.finish(h)
-        self._handles.clear()
+        self._finish_exchange()
         if not self._final:
             self.eng.commit_masks()                     # a micro-step that only accumulates: no update, fresh dropout bits
         elif gc is None:
@@ -354,14 +359,16 @@ class ConcurrentSampler:
     independent and a single chain's kernels leave most of the machine idle at the low-resolution stages, so chains on
     different streams fill each other's gaps.  sample() returns the [streams * n, C, H, W] result."""
 
-    def __init__(self, ddpm, n: int, shape, streams: int = 2, *, use_graph: bool = True):
+    def __init__(self, ddpm, n: int, shape, streams: int = 2, *, use_graph: bool = True, first_image: int = 0,
+                 seed: Optional[int] = None):
         self.ddpm = ddpm
         self.streams = [torch.cuda.Stream() for _ in range(streams)]
         self.samplers = []
-        for s in self.streams:
+        for k, s in enumerate(self.streams):
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.samplers.append(GraphedSampler(ddpm, n, shape, use_graph=use_graph, stream=s, own_engine=True))
+                self.samplers.append(GraphedSampler(ddpm, n, shape, use_graph=use_graph, stream=s, own_engine=True,
+                                                    first_image=first_image + k * n, seed=seed))
         for s in self.streams:
             torch.cuda.current_stream().wait_stream(s)
 
@@ -382,11 +389,21 @@ class ConcurrentSampler:
 
 
 class GraphedSampler:
-    """One sampling step (UNet forward + reverse step + t -= 1) captured once and replayed T times per chain."""
+    """One sampling step (UNet forward + reverse step + t -= 1) captured once and replayed T times per chain.
 
-    def __init__(self, ddpm, n: int, shape, *, use_graph: bool = True, stream=None, own_engine: bool = True):
+    seed / first_image make a sampling job independent of how it is split: with a job seed, the start tensor and every
+    step's noise are Philox draws keyed by (seed, chain number, step, GLOBAL element index), the sampler holding images
+    first_image .. first_image + n - 1 of the job.  Two GPUs sampling images [0, n) and [n, 2n) with the same seed then draw
+    exactly the numbers one GPU sampling [0, 2n) draws.  Without a seed the sampler owns a private random stream."""
+
+    _CHAIN_STRIDE = 0x632BE59BD9B4E019            # seed distance between consecutive chains of one job
+
+    def __init__(self, ddpm, n: int, shape, *, use_graph: bool = True, stream=None, own_engine: bool = True,
+                 first_image: int = 0, seed: Optional[int] = None):
         from torch.nn.modules.utils import _pair
         self.ddpm = ddpm
+        self.job_seed = None if seed is None else int(seed)
+        self._chains = 0
         # The sampler drives an engine of its own: the kernel-layout weight copies are refreshed once per chain (begin)
         # instead of inside every captured step, and samplers on different streams do not share per-shape bookkeeping.
         self._engine = None
@@ -396,6 +413,9 @@ class GraphedSampler:
         dev = next(ddpm.parameters()).device
         self.seed = torch.randint(0, 2 ** 62, (1,), device=dev, dtype=torch.long)     # this chain's noise stream
         self.x = torch.zeros((n, ddpm.img_channels) + _pair(shape), device=dev)
+        self.first_index = int(first_image) * (self.x.numel() // n)
+        if self.first_index % 4:
+            raise ValueError("GraphedSampler: first_image * C * H * W must be a multiple of 4")
         self.x_next = torch.empty_like(self.x)
         self.times = torch.zeros(n, device=dev, dtype=torch.long)
         self.graph = None
@@ -423,10 +443,16 @@ class GraphedSampler:
 
     def begin(self, x_T: Optional[Tensor] = None):
         """start a chain: x_T (or fresh noise), t = T, current weights"""
-        if x_T is None:
+        if self.job_seed is not None:
+            self.seed.fill_((self.job_seed + self._chains * self._CHAIN_STRIDE) & (2 ** 62 - 1))
+            self._chains += 1
+        if x_T is not None:
+            self.x.copy_(x_T)
+        elif self.job_seed is None:
             self.x.normal_()
         else:
-            self.x.copy_(x_T)
+            from . import hip
+            hip.call("ddpm_fill_normal", hip.ptr(self.x), self.x.numel(), hip.ptr(self.seed), 1, self.first_index, hip.stream())
         self.times.fill_(self.ddpm.T)
         if self._engine is not None:
             self._engine.wc.refresh(self._params(), self.x.device, force=True)
@@ -439,7 +465,8 @@ class GraphedSampler:
 
     def _body(self):
         x0_pred = self._forward()
-        self.ddpm.reverse_q(self.x, x0_pred, self.times, out=self.x_next, _sigmoid=self.bce, _seed=self.seed)
+        self.ddpm.reverse_q(self.x, x0_pred, self.times, out=self.x_next, _sigmoid=self.bce, _seed=self.seed,
+                            _first_index=self.first_index)
         self.x.copy_(self.x_next)
         self.times -= 1
 

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libddpm_hip.so")
 ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5, "hardsigmoid": 6, "relu6": 7, "leaky_relu": 8, "selu": 9}
 CONV_3X3_S1, CONV_3X3_S2, CONV_1X1, CONVT_2X2_S2, DGRAD_3X3_S2, DGRAD_CONVT_2X2 = range(6)
 OUT_BF16_NHWC, OUT_F32_NCHW = 0, 1
+CONV_KERNEL_NAMES = {0: "conv_mfma_kernel", 1: "conv_mfma_kernel", 2: "conv_small_kernel", 3: "conv_thin_kernel", 4: "conv_img_kernel"}
 
 _vp, _i, _f, _i64, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint32
 
@@ -104,7 +105,8 @@ class WgradDesc(C.Structure):
 _PROTOS = {
     "ddpm_abi_version": ([], _i),
     "ddpm_q_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _u32, _vp], _i),
-    "ddpm_reverse_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _u32, _i, _vp], _i),
+    "ddpm_reverse_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _u32, _i, C.c_uint64, _vp], _i),
+    "ddpm_fill_normal": ([_vp, _i64, _vp, _u32, C.c_uint64, _vp], _i),
     "ddpm_elbo_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
     "ddpm_elbo_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
     "ddpm_time_embedding": ([_vp, _f, _i, _vp, _i, _vp], _i),
@@ -117,6 +119,7 @@ _PROTOS = {
     "ddpm_prepare_images": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "ddpm_conv_forward": ([C.POINTER(ConvDesc), _vp], _i),
     "ddpm_conv_debug_tile": ([_i], _i),
+    "ddpm_conv_last_kernel": ([], _i),
     "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_conv_gnb_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),

@@ -98,7 +98,8 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
         return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out, y, stats, None if gn is None else gn[4]) + wbytes + cout * 4 + obytes + extra,
                 2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}")
 
-    _launch("conv_mfma_kernel", cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
+    # which of the convolution kernels takes the launch is the library's choice: the probe asks after the call
+    _launch(lambda: hip.CONV_KERNEL_NAMES[hip.lib().ddpm_conv_last_kernel()], cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
     if act2 is not None:
         return out, y
     return out if gn is None else (out, y, stats)

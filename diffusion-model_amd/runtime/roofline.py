@@ -35,7 +35,7 @@ class _Probe:
         e0.record()
         fn()
         e1.record()
-        self.rows.append((kernel, e0, e1) + tuple(cost()))
+        self.rows.append((kernel() if callable(kernel) else kernel, e0, e1) + tuple(cost()))
 
 
 def measure(step: Callable[[], None], reps: int = 3, traffic_file: str = "", detail: list = None) -> Dict:

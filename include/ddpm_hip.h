@@ -54,10 +54,15 @@ int ddpm_q_sample(const float* x0, const int64_t* t, const float* noise, const f
                   int cpad, int N, int C, int HW, const uint64_t* seed, uint32_t stream_id, ddpm_stream_t stream);
 
 /* DDPM.reverse_q (ddpm.py:113-144): out = A_t x_t + B_t x0_pred + C_t z.  sigmoid_pred applies the "bce" branch
- * of DDPM.sample (ddpm.py:158-159) to x0_pred first. */
+ * of DDPM.sample (ddpm.py:158-159) to x0_pred first.  z drawn in-kernel (noise == NULL) is the Philox sample of GLOBAL flat
+ * element first_index + i (a multiple of 4): a rank that holds images [b, e) of a sharded sampling job passes
+ * first_index = b * chw and draws exactly the numbers a single GPU would draw for those images. */
 int ddpm_reverse_step(const float* xt, const float* x0_pred, const int64_t* t, const float* noise, const float* sched,
                       float* out, int N, int64_t chw, const uint64_t* seed, uint32_t stream_id, int sigmoid_pred,
-                      ddpm_stream_t stream);
+                      uint64_t first_index, ddpm_stream_t stream);
+/* out[i] = N(0,1) sample of global flat element first_index + i of stream stream_id of the (*seed) sequence: the start tensor
+ * X_T of DDPM.sample (ddpm.py:152: randn), keyed like the reverse step's noise.  n and first_index multiples of 4. */
+int ddpm_fill_normal(float* out, int64_t n, const uint64_t* seed, uint32_t stream_id, uint64_t first_index, ddpm_stream_t stream);
 
 /* ELBOLoss.forward (losses/ELBO.py:36-76): *loss = mean(w_t * l(pred, target)), l = squared error (bce=0) or
  * BCE-with-logits (bce=1); weighted=0 is the use_elbo=False branch. */
@@ -151,6 +156,11 @@ int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream);
  * of the calling thread use that tile or fail; 0 restores the automatic choice; -1 changes nothing.  Returns the code of the
  * tile the thread's last general-kernel launch used (0 if none). */
 int ddpm_conv_debug_tile(int force);
+/* Which kernel the calling thread's last ddpm_conv_forward ran on (measurement and test hook, no reference counterpart):
+ * the general tap-list kernel, the split-K kernel of 3x3 convolutions on 2x2 / 4x4 / 8x8 images, the vector-ALU kernel of the
+ * image ends, or the whole-image kernel that finishes the unit's GroupNorm (or its backward) in the same launch. */
+enum { DDPM_CONV_KERNEL_NONE = 0, DDPM_CONV_KERNEL_GENERAL = 1, DDPM_CONV_KERNEL_SMALL = 2, DDPM_CONV_KERNEL_THIN = 3, DDPM_CONV_KERNEL_IMAGE = 4 };
+int ddpm_conv_last_kernel(void);
 
 /* ---- GroupNorm + activation (+ dropout mask, + residual) on NHWC bf16 (groupnorm.hip) ------------- */
 

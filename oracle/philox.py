@@ -34,3 +34,21 @@ def sample_timesteps(n: int, T: int, seed: int, stream_id: int) -> np.ndarray:
     q = np.arange((n + 3) // 4, dtype=np.uint64)
     words = np.stack(philox4x32_10(q, 0, stream_id, 0x3C6EF372, seed & 0xFFFFFFFF, seed >> 32), axis=1).reshape(-1)[:n]
     return (1 + ((words.astype(np.uint64) * np.uint64(T)) >> np.uint64(32))).astype(np.int64)
+
+
+def normal(n: int, seed: int, stream_id: int, first_index: int = 0) -> np.ndarray:
+    """N(0,1) samples of GLOBAL flat elements first_index .. first_index + n - 1 (both multiples of 4) of the (seed,
+    stream) sequence: Philox block q = element // 4, words (x, y) and (z, w) through Box-Muller with u in (0, 1] for the
+    radius and [0, 1) for the angle, outputs ordered (r0 cos, r0 sin, r1 cos, r1 sin).  float32 arithmetic with numpy's
+    log/sin/cos: the HIP kernel's fast log/sincos differ from these in the last bits, so compare with a tolerance."""
+    assert n % 4 == 0 and first_index % 4 == 0
+    seed &= 0xFFFFFFFFFFFFFFFF
+    q = np.arange(n // 4, dtype=np.uint64) + np.uint64(first_index // 4)
+    x, y, z, w = philox4x32_10(q & MASK, q >> np.uint64(32), stream_id, 0x6A09E667, seed & 0xFFFFFFFF, seed >> 32)
+    k = np.float32(2.3283064365386963e-10)
+    f = lambda v: v.astype(np.float32)          # noqa: E731  (uint32 -> float32 rounds to nearest, as the device cast does)
+    u0, u1, u2, u3 = (f(x) + np.float32(1)) * k, f(y) * k, (f(z) + np.float32(1)) * k, f(w) * k
+    ra, rb = np.sqrt(np.float32(-2) * np.log(u0)), np.sqrt(np.float32(-2) * np.log(u2))
+    two_pi = np.float32(6.283185307179586)
+    out = np.stack([ra * np.cos(two_pi * u1), ra * np.sin(two_pi * u1), rb * np.cos(two_pi * u3), rb * np.sin(two_pi * u3)], axis=1)
+    return out.reshape(-1).astype(np.float32)

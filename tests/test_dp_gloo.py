@@ -4,6 +4,7 @@ broadcast and the sampling shard split.  Mirrors what the reference gets from to
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as td
 import torch.multiprocessing as mp
@@ -57,8 +58,29 @@ def _worker(rank, world, port, q):
         # (4) sharded sampling: every rank produces its share (here: images filled with their global index), rank 0 receives all
         total = 5
         b0, _ = shard_range(total, rank, world)
-        imgs = sample_sharded(lambda n: (torch.arange(n, dtype=torch.float32) + b0).view(n, 1, 1, 1).expand(n, 1, 2, 2).contiguous(), total)
-        ok4 = (imgs is None) if rank else (imgs.shape == (total, 1, 2, 2) and torch.equal(imgs[:, 0, 0, 0], torch.arange(total, dtype=torch.float32)))
+        firsts = []
+
+        def fake(n, first):
+            firsts.append(first)
+            return (torch.arange(n, dtype=torch.float32) + first).view(n, 1, 1, 1).expand(n, 1, 2, 2).contiguous()
+
+        imgs = sample_sharded(fake, total)
+        ok4 = firsts == [b0] and ((imgs is None) if rank else (imgs.shape == (total, 1, 2, 2) and
+                                                                torch.equal(imgs[:, 0, 0, 0], torch.arange(total, dtype=torch.float32))))
+        # (5) noise keyed by GLOBAL image index makes the job independent of the world size: a stand-in chain (x_T and three
+        # noisy steps, all Philox draws at the global element index, the keying the HIP sampler uses) sharded over the ranks
+        # equals the same chain computed in one piece
+        from oracle import philox
+        chw = 8
+
+        def chain(n, first, seed=77):
+            x = philox.normal(n * chw, seed, 1, first * chw)
+            for k in range(3):
+                x = np.float32(0.9) * x + np.float32(0.1) * philox.normal(n * chw, seed + 1000 * (k + 1), 2, first * chw)
+            return torch.from_numpy(x).view(n, 2, 2, 2)
+
+        got = sample_sharded(chain, total)
+        ok4 = ok4 and ((got is None) if rank else torch.equal(got, chain(total, 0)))
         q.put((rank, sums, ok1, ok2 and ok3 and ok4))
     finally:
         td.destroy_process_group()

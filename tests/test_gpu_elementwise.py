@@ -48,7 +48,7 @@ def test_q_and_reverse_bit_exact_vs_golden(golden, dev):
     out = torch.empty_like(x0)
     x0p, z = g["x0_pred"].to(dev), g["z"].to(dev)       # keep references: only raw pointers cross the ABI
     hip.call("ddpm_reverse_step", hip.ptr(xt), hip.ptr(x0p), hip.ptr(t), hip.ptr(z), hip.ptr(tab),
-             hip.ptr(out), n, c * h * w, None, 0, 0, hip.stream())
+             hip.ptr(out), n, c * h * w, None, 0, 0, 0, hip.stream())
     same(out.cpu(), g["x_prev"])
 
 

@@ -554,3 +554,138 @@ def test_pipelined_step_draws_dropout_bits_one_step_ahead(dev):
     for _ in range(40):
         last = step.replay().item()
     assert last < losses[0]
+
+
+def test_fused_adam_follows_lr_scheduler(dev):
+    """The reference trainer always attaches CosineAnnealingLR (base_trainer.py:109-115 there), which writes
+    param_groups[0]['lr']: FusedAdam's device-resident rate must follow it, in eager steps and under the captured step of
+    the graph drivers, exactly like torch.optim.Adam does."""
+    from dm_amd.optimizer import FusedAdam
+    from dm_amd.runtime import graphs
+    ma, _, _ = build(dev, 1, "gelu")
+    mb, _, _ = build(dev, 1, "gelu")
+    oa = torch.optim.Adam(ma.parameters(), lr=1e-3)
+    ob = FusedAdam(mb.parameters(), lr=1e-3)
+    sa = torch.optim.lr_scheduler.CosineAnnealingLR(oa, T_max=4, eta_min=1e-5)
+    sb = torch.optim.lr_scheduler.CosineAnnealingLR(ob, T_max=4, eta_min=1e-5)
+    crit = ELBOLoss("mse")
+    x0 = (hash_uniform((4, 1, 32, 32), 5) * 2 - 1).to(dev)
+    ma.eval(); mb.eval()
+    for it in range(4):
+        t = torch.tensor([3, 40, 80, 120], device=dev)
+        noise = hash_normal((4, 1, 32, 32), 50 + it).to(dev)
+        lr_now = oa.param_groups[0]["lr"]
+        for m, o, s in ((ma, oa, sa), (mb, ob, sb)):
+            o.zero_grad(set_to_none=True)
+            crit(m, t, m(m.q(x0, t, noise=noise), t), x0)["Loss"].backward()
+            o.step()
+            s.step()
+        assert abs(float(ob._lr.item()) - lr_now) < 1e-9        # the step just taken used the rate the scheduler had set for it
+        assert it == 0 or lr_now < 1e-3
+    assert abs(ob.param_groups[0]["lr"] - oa.param_groups[0]["lr"]) < 1e-12
+    for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert l2_err(pb.detach().cpu(), pa.detach().cpu()) < 2e-3, k
+    # captured step: the rate a scheduler sets between replays is the one the replayed Adam uses
+    m, _, _ = build(dev, 1, "gelu", drop_p=0.0)
+    m.train()
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    step = graphs.PipelinedTrainStep(m, crit, opt, x0.repeat(2, 1, 1, 1), None, phases=4)
+    w0 = [p.detach().clone() for p in m.parameters()]
+    opt.param_groups[0]["lr"] = 0.0                     # what a scheduler does
+    step.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(p.detach(), w) for p, w in zip(m.parameters(), w0)), "the captured Adam step ignored the new learning rate"
+    opt.param_groups[0]["lr"] = 1e-3
+    step.replay()
+    torch.cuda.synchronize()
+    assert any(not torch.equal(p.detach(), w) for p, w in zip(m.parameters(), w0))
+    with pytest.raises(ValueError, match="one hyper-parameter set"):
+        FusedAdam([{"params": [torch.nn.Parameter(torch.zeros(4, device=dev))], "lr": 1e-3},
+                   {"params": [torch.nn.Parameter(torch.zeros(4, device=dev))], "lr": 1e-4}])
+
+
+def test_stock_ddp_wrap_of_the_dropin_module(dev):
+    """The reference trainer wraps the model in torch's DistributedDataParallel (base_trainer.py:95-100 there) and passes the
+    wrapper to the criterion with is_ddp=True.  On a one-rank RCCL group the wrapped drop-in module must give the same loss
+    and gradients as the bare one (DDP's reducer sees the 350 parameter gradients of the single autograd node)."""
+    import os
+    import torch.distributed as td
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29535")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ma, _, _ = build(dev, 3, "gelu")
+        mb, _, _ = build(dev, 3, "gelu")
+        ma.eval(); mb.eval()
+        wrapped = DDP(mb, device_ids=[dev.index])
+        crit = ELBOLoss("mse")
+        x0 = (hash_uniform((4, 3, 32, 32), 5) * 2 - 1).to(dev)
+        t = torch.tensor([3, 40, 80, 120], device=dev)
+        noise = hash_normal((4, 3, 32, 32), 51).to(dev)
+        x_t = ma.q(x0, t, noise=noise)
+        la = crit(ma, t, ma(x_t, t), x0, is_ddp=False)["Loss"]
+        la.backward()
+        lb = crit(wrapped, t, wrapped(wrapped.module.q(x0, t, noise=noise), t), x0, is_ddp=True)["Loss"]
+        lb.backward(retain_graph=True)
+        assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+        for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            assert pb.grad is not None and l2_err(pb.grad.cpu(), pa.grad.cpu()) < 1e-3, k
+        assert len(wrapped.state_dict()) == 350
+    except BaseException as exc:
+        import traceback
+        traceback.print_exc()
+        raise exc
+    finally:
+        torch.cuda.synchronize()
+        td.destroy_process_group()
+
+
+def test_sampling_noise_is_keyed_by_global_image_index(dev):
+    """A sampling job split over GPUs draws, for image i, the numbers one GPU would draw for image i: the start tensor and
+    each step's noise are Philox draws at the GLOBAL element index (oracle/philox.py restates the mapping).  Shards of a
+    draw concatenate bit for bit to the whole draw; two 2-image samplers at first_image 0 and 2 reproduce a 2x2 concurrent
+    sampler's full chain bit for bit (same per-launch batch, hence the same kernels), and a 4-image sampler's to rounding
+    (a different batch picks different convolution tiles)."""
+    from dm_amd.runtime import graphs, hip
+    from oracle import philox
+    seed = torch.tensor([0x1234_5678_9ABC], device=dev, dtype=torch.long)
+    whole = torch.empty(4096, device=dev)
+    hip.call("ddpm_fill_normal", hip.ptr(whole), 4096, hip.ptr(seed), 1, 0, hip.stream())
+    part = torch.empty(1024, device=dev)
+    hip.call("ddpm_fill_normal", hip.ptr(part), 1024, hip.ptr(seed), 1, 2048, hip.stream())
+    assert torch.equal(part, whole[2048:3072])
+    want = torch.from_numpy(philox.normal(1024, 0x1234_5678_9ABC, 1, 2048))
+    assert (part.cpu() - want).abs().max() < 1e-3          # fast log / sincos on the device, numpy's on the host
+    assert abs(float(whole.mean())) < 0.06 and abs(float(whole.std()) - 1) < 0.05
+
+    m, _, _ = build(dev, 1, "gelu", head_gain=0.3)
+    m.eval()
+    job = 424242
+    lo = graphs.GraphedSampler(m, 2, (32, 32), seed=job, first_image=0)
+    hi = graphs.GraphedSampler(m, 2, (32, 32), seed=job, first_image=2)
+    full = graphs.GraphedSampler(m, 4, (32, 32), seed=job)
+    for s in (lo, hi, full):
+        s.begin()
+    assert torch.equal(torch.cat([lo.x, hi.x]), full.x)
+    for _ in range(3):
+        for s in (lo, hi, full):
+            s.step()
+    assert (torch.cat([lo.x, hi.x]) - full.x).abs().max() < 2e-2
+    assert not torch.equal(lo.x, hi.x)
+    # the reverse step's noise alone (same inputs, shard vs whole) is bit-exact
+    x = hash_normal((4, 1, 32, 32), 5).to(dev)
+    p = hash_normal((4, 1, 32, 32), 6).to(dev)
+    t = torch.full((4,), 60, device=dev, dtype=torch.long)
+    s1, s2 = seed.clone(), seed.clone()
+    o_full = m.reverse_q(x, p, t, _seed=s1)
+    o_hi = m.reverse_q(x[2:], p[2:], t[2:], _seed=s2, _first_index=2 * 1024)
+    assert torch.equal(o_hi, o_full[2:])
+    # whole chains: concurrent 2 x 2 equals the two stand-alone samplers
+    cs = graphs.ConcurrentSampler(m, 2, (32, 32), streams=2, seed=job)
+    out = cs.sample()
+    a, b = lo.sample().clone(), hi.sample().clone()        # second chain of lo/hi: chain number 1 ...
+    out2 = cs.sample()                                     # ... as is the concurrent sampler's second chain
+    torch.cuda.synchronize()
+    assert torch.equal(out2, torch.cat([a, b]))
+    assert not torch.equal(out, out2)                      # consecutive chains of one job differ

@@ -135,3 +135,17 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     r = subprocess.run([sys.executable, bench, "--gpus", "1", "--dry-launch"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
+
+
+def test_sample_bytes_truncate_like_to_pil_image(golden):
+    """DDPM.sample ends in torchvision's to_pil_image (utils/other_utils.py:14-37 of the reference), whose float -> byte
+    step is pic.mul(255).byte(): a truncation.  The byte image of the reference chain's final tensor must equal that
+    arithmetic applied to the fixture's own [0, 1]-clamped result, bit for bit (torchvision is not installed here, so the
+    PIL object itself is not compared: parity of that last hop is unpinned)."""
+    g = golden("sample_chain.pt")
+    final = g["snapshots"][120]
+    want = g["final_unit"].mul(255).byte()
+    got = dm_ddpm.DDPM.to_uint8(final.clone())
+    assert got.dtype == torch.uint8 and torch.equal(got, want)
+    x = torch.tensor([[-1.0, -0.999, 0.0, 0.5, 0.9999, 1.0, 3.0]])
+    assert dm_ddpm.DDPM.to_uint8(x).tolist() == [[0, 0, 127, 191, 254, 255, 255]]

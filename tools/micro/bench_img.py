@@ -13,6 +13,7 @@ dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 K33, K33S2, KT = hip.CONV_3X3_S1, hip.CONV_3X3_S2, hip.CONVT_2X2_S2
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 32       # input image size of the network: stage resolutions scale with it
 FWD = [("a s2 32->32 32^2", K33S2, 32, 32, 32), ("b 3x3 32->32 16^2", K33, 32, 32, 16), ("c s2 32->64 16^2", K33S2, 32, 64, 16),
        ("d s2 64->128 8^2", K33S2, 64, 128, 8), ("e s2 128->256 4^2", K33S2, 128, 256, 4), ("f convT 256->128 2^2", KT, 256, 128, 2),
        ("g convT 128->64 4^2", KT, 128, 64, 4), ("h convT 64->32 8^2", KT, 64, 32, 8), ("j convT 32->32 16^2", KT, 32, 32, 16)]
@@ -39,8 +40,10 @@ def timeit(fn, reps=20):
 
 
 for tag, kind, ci, co, h in FWD:
-    if ONLY and not tag.startswith(ONLY):
+    if ONLY and ONLY != "-" and not tag.startswith(ONLY):
         continue
+    h = h * S // 32
+    tag = f"{tag.split()[0]} {tag.split()[1]} {tag.split()[2]} {h}^2"
     k = 2 if kind == KT else 3
     x = torch.randn(N, h, h, ci, device=dev).bfloat16()
     w = torch.randn((ci, co, k, k) if kind == KT else (co, ci, k, k), device=dev) * 0.05

@@ -8,10 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 python3 -u $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-200
 rm -rf /tmp/prof && mkdir -p /tmp/prof
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-sample --no-cpu --no-roofline > $OUT/bench_under_rocprof.json 2> /tmp/prof/stats.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-sample --no-cpu --no-roofline --no-extra > $OUT/bench_under_rocprof.json 2> /tmp/prof/stats.err
 python3 $R/tools/profile_summary.py stats /tmp/prof/stats $OUT/kernel_stats.csv
 python3 $R/tools/micro/timeline.py $(find /tmp/prof/stats -name '*kernel_trace.csv' | head -1) > $OUT/timeline.txt
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/fetch -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph > /tmp/prof/fetch.out 2> /tmp/prof/fetch.err
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/write -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph > /tmp/prof/write.out 2> /tmp/prof/write.err
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/fetch -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph --no-extra > /tmp/prof/fetch.out 2> /tmp/prof/fetch.err
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/write -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph --no-extra > /tmp/prof/write.out 2> /tmp/prof/write.err
 python3 $R/tools/profile_summary.py traffic /tmp/prof/fetch /tmp/prof/write $OUT/hbm_traffic.json
+# matrix-core evidence: one counter pass of its own (no trace domains beside --pmc), the program directly after --
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof/mfma -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph --no-extra > /tmp/prof/mfma.out 2> /tmp/prof/mfma.err
+python3 $R/tools/profile_summary.py mfma /tmp/prof/mfma /tmp/prof/stats $OUT/mfma_util.json
 ls -la $OUT
