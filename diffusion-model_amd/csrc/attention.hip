@@ -483,6 +483,8 @@ struct SnArgs {
     float* part;               // [N][3][C]: d gamma, d beta, column sums of da
     int N, S, C, act;
     float eps;
+    const float* act_beta;     // swish / hardswish: the activation's learnable scalar
+    float* dbeta_part;         // backward, swish / hardswish: [N] per-sample sums of da-terms of the scalar's gradient
 };
 
 constexpr int SN_THREADS = 512;
@@ -524,10 +526,10 @@ __device__ __forceinline__ void block_colsum512(float (&v)[8], int vps, float* s
     }
 }
 
-__device__ __forceinline__ void sn_u(const SnArgs& a, long long e, float (&u)[8], float (&av)[8]) {
+__device__ __forceinline__ void sn_u(const SnArgs& a, long long e, float (&u)[8], float (&av)[8], float bsc) {
     const bf16x8 x = *(const bf16x8*)(a.a + e);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { av[j] = (float)x[j]; u[j] = act_fwd(av[j], a.act); }
+    for (int j = 0; j < 8; ++j) { av[j] = (float)x[j]; u[j] = act_fwd(av[j], a.act, bsc); }
     if (a.b) {
         const bf16x8 r = *(const bf16x8*)(a.b + e);
 #pragma unroll
@@ -540,10 +542,11 @@ __global__ __launch_bounds__(SN_THREADS) void sample_norm_fwd_kernel(const SnArg
     const int tid = threadIdx.x, n = blockIdx.x;
     const int vps = a.C / 8, cv = tid % vps, prow = tid / vps, pstep = SN_THREADS / vps;
     const long long base = (long long)n * a.S * a.C + cv * 8;
+    const float bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
     float s = 0.f, ss = 0.f;
     for (int p = prow; p < a.S; p += pstep) {
         float u[8], av[8];
-        sn_u(a, base + (long long)p * a.C, u, av);
+        sn_u(a, base + (long long)p * a.C, u, av, bsc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s += u[j]; ss += u[j] * u[j]; }
     }
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(SN_THREADS) void sample_norm_fwd_kernel(const SnArg
     for (int p = prow; p < a.S; p += pstep) {
         const long long e = base + (long long)p * a.C;
         float u[8], av[8];
-        sn_u(a, e, u, av);
+        sn_u(a, e, u, av, bsc);
         bf16x8 w;
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = (bf16)(u[j] * sc[j] + sh[j]);
@@ -580,6 +583,9 @@ __global__ __launch_bounds__(SN_THREADS) void sample_norm_bwd_kernel(const SnArg
     const int vps = a.C / 8, cv = tid % vps, prow = tid / vps, pstep = SN_THREADS / vps;
     const long long base = (long long)n * a.S * a.C + cv * 8;
     const float mean = a.stats[n * 2], rstd = a.stats[n * 2 + 1];
+    const bool hb = ACT_HAS_BETA(a.act);
+    const float bsc = hb ? *a.act_beta : 1.f;
+    float sb = 0.f;
     float ga[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) ga[j] = a.gamma[cv * 8 + j];
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(SN_THREADS) void sample_norm_bwd_kernel(const SnArg
     for (int p = prow; p < a.S; p += pstep) {
         const long long e = base + (long long)p * a.C;
         float u[8], av[8];
-        sn_u(a, e, u, av);
+        sn_u(a, e, u, av, bsc);
         const bf16x8 dv = *(const bf16x8*)(a.dy + e);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -605,14 +611,15 @@ __global__ __launch_bounds__(SN_THREADS) void sample_norm_bwd_kernel(const SnArg
     for (int p = prow; p < a.S; p += pstep) {
         const long long e = base + (long long)p * a.C;
         float u[8], av[8];
-        sn_u(a, e, u, av);
+        sn_u(a, e, u, av, bsc);
         const bf16x8 dv = *(const bf16x8*)(a.dy + e);
         bf16x8 wu, wa;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xh = (u[j] - mean) * rstd;
             const float du = rstd * ((float)dv[j] * ga[j] - s1 - xh * s2);
-            const float da = du * act_bwd(av[j], a.act);
+            const float da = du * act_bwd(av[j], a.act, bsc);
+            if (hb) sb += du * act_dbeta(av[j], a.act, bsc);
             dbias[j] += da;
             wu[j] = (bf16)du; wa[j] = (bf16)da;
         }
@@ -630,6 +637,10 @@ __global__ __launch_bounds__(SN_THREADS) void sample_norm_bwd_kernel(const SnArg
             a.part[((long long)n * 3 + 2) * a.C + tid * 8 + j] = dbias[j];
         }
     }
+    if (hb) {
+        sb = block_sum512(sb, s_w, tid);
+        if (tid == 0) a.dbeta_part[n] = sb;
+    }
 }
 
 static int sn_prepare(SnArgs& a, const ddpm_sample_norm_desc* d, bool bwd, const char* what) {
@@ -640,6 +651,10 @@ static int sn_prepare(SnArgs& a, const ddpm_sample_norm_desc* d, bool bwd, const
     a.a = (const bf16*)d->a; a.b = (const bf16*)d->b; a.gamma = d->gamma; a.beta = d->beta; a.y = (bf16*)d->y; a.stats = d->stats;
     a.dy = (const bf16*)d->dy; a.du = (bf16*)d->du; a.da = (bf16*)d->da; a.part = d->part;
     a.N = d->N; a.S = d->S; a.C = d->C; a.act = d->act; a.eps = d->eps;
+    a.act_beta = d->act_beta; a.dbeta_part = d->dbeta_part;
+    DDPM_REQUIRE(d->act >= 0 && d->act <= ACT_LAST, "%s: unknown activation %d", what, d->act);
+    DDPM_REQUIRE(!ACT_HAS_BETA(d->act) || (d->act_beta && (!bwd || d->dbeta_part)),
+                 "%s: swish / hardswish need their scalar (act_beta) and, backward, the [N] workspace of its gradient", what);
     if (!bwd) DDPM_REQUIRE(d->y && d->beta, "%s: null output / beta", what);
     else DDPM_REQUIRE(d->dy && d->du && d->part, "%s: null gradient pointer", what);
     return DDPM_OK;

@@ -16,7 +16,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // Activation codes shared by every kernel and by the host side.
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5, ACT_HARDSIGMOID = 6, ACT_RELU6 = 7,
-       ACT_LEAKY_RELU = 8, ACT_SELU = 9, ACT_LAST = 9 };
+       ACT_LEAKY_RELU = 8, ACT_SELU = 9,
+       // the two with a learnable scalar b (neural_nets/activations.py:25-63 of the reference): z * sigmoid(b z), z * hardsigmoid(b z)
+       ACT_SWISH = 10, ACT_HARDSWISH = 11, ACT_LAST = 11 };
+#define ACT_HAS_BETA(act) ((act) == ACT_SWISH || (act) == ACT_HARDSWISH)
 #define SELU_SCALE 1.0507009873554805f
 #define SELU_ALPHA 1.6732632423543772f
 #define LEAKY_SLOPE 0.05f   /* the reference registry's leaky_relu slope (neural_nets/activations.py:110) */
@@ -88,6 +91,40 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
         case ACT_SELU: return z > 0.f ? SELU_SCALE : SELU_SCALE * SELU_ALPHA * __expf(z);
         default: return 1.f;
     }
+}
+
+// The same with the activation's learnable scalar b (ignored by the parameter-free codes).
+__device__ __forceinline__ float hardsigmoid_of(float u) { return fminf(fmaxf(u + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+
+__device__ __forceinline__ float act_fwd(float z, int act, float b) {
+    if (act == ACT_SWISH) return z * sigmoid_fast(b * z);
+    if (act == ACT_HARDSWISH) return z * hardsigmoid_of(b * z);
+    return act_fwd(z, act);
+}
+
+__device__ __forceinline__ float act_bwd(float z, int act, float b) {
+    if (act == ACT_SWISH) {
+        const float s = sigmoid_fast(b * z);
+        return s * (1.0f + b * z * (1.0f - s));
+    }
+    if (act == ACT_HARDSWISH) {
+        const float u = b * z;
+        return hardsigmoid_of(u) + ((u > -3.f && u < 3.f) ? u * (1.f / 6.f) : 0.f);
+    }
+    return act_bwd(z, act);
+}
+
+// d act(z; b) / db
+__device__ __forceinline__ float act_dbeta(float z, int act, float b) {
+    if (act == ACT_SWISH) {
+        const float s = sigmoid_fast(b * z);
+        return z * z * s * (1.0f - s);
+    }
+    if (act == ACT_HARDSWISH) {
+        const float u = b * z;
+        return (u > -3.f && u < 3.f) ? z * z * (1.f / 6.f) : 0.f;
+    }
+    return 0.f;
 }
 
 // Runs f(integral_constant<int, A>) with A = the activation code when it is one of the hot ones (gelu, silu, none), so that

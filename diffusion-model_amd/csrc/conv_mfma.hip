@@ -388,6 +388,8 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.out_mode = d->out_mode; a.sum_out = d->sum_out;
     a.out2 = (bf16*)d->out2; a.act2 = d->act2;
     DDPM_REQUIRE(!d->out2 || (d->out_mode == OUT_BF16_NHWC && d->Cout % 8 == 0 && d->act == 0), "conv: the second (activated) result needs an NHWC bf16 output, Cout %% 8 == 0 and no first activation");
+    DDPM_REQUIRE(!ACT_HAS_BETA(d->act) && !ACT_HAS_BETA(d->act2) && !ACT_HAS_BETA(d->gn_act) && !ACT_HAS_BETA(d->gnb_act),
+                 "conv: swish / hardswish (learnable scalar) are not fused into the convolution launches; apply them with ddpm_gn_act_forward / _backward");
 
     const int npix = a.g.NB * a.g.PH * a.g.PW;
     const int bm = 32 * cfg.wm, bn = 32 * cfg.nt * cfg.wn;

@@ -349,7 +349,10 @@ static int small_gnb_fusable(const ddpm_conv_desc* d) {
 }
 
 // Whether the GroupNorm backward described by the gnb_* fields can run in the loader of this (data-gradient) launch.
-extern "C" int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d) { return small_gnb_fusable(d) || (d && ddpm_conv_img_fusable(d, 1)); }
+extern "C" int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d) {
+    if (d && ACT_HAS_BETA(d->gnb_act)) return 0;          // an activation with a learnable scalar needs that scalar's gradient too
+    return small_gnb_fusable(d) || (d && ddpm_conv_img_fusable(d, 1));
+}
 
 static int small_gn_fusable(const ddpm_conv_desc* d) {
     if (!d || d->kind != CONV_3X3_S1 || d->IH != d->IW || (d->IW != 2 && d->IW != 4 && d->IW != 8)) return 0;
@@ -363,7 +366,10 @@ static int small_gn_fusable(const ddpm_conv_desc* d) {
 }
 
 // Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
-extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) { return small_gn_fusable(d) || (d && ddpm_conv_img_fusable(d, 0)); }
+extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
+    if (d && ACT_HAS_BETA(d->gn_act)) return 0;
+    return small_gn_fusable(d) || (d && ddpm_conv_img_fusable(d, 0));
+}
 
 // Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
 int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {

@@ -363,7 +363,7 @@ extern "C" int ddpm_act_backward(const void* x, const void* dy, void* dx, float*
     DDPM_REQUIRE(x && dy && dx && part && N > 0 && HW > 0, "act_backward: bad arguments");
     DDPM_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "act_backward: C must be 8, 16, 32 or 64 (got %d)", C);
     DDPM_REQUIRE(P > 0 && HW % P == 0 && (long long)N * P < (1ll << 31), "act_backward: P (%d) must divide H*W (%d)", P, HW);
-    DDPM_REQUIRE(act >= 0 && act <= ACT_LAST, "act_backward: unknown activation %d", act);
+    DDPM_REQUIRE(act >= 0 && act <= ACT_LAST && !ACT_HAS_BETA(act), "act_backward: unknown activation %d (swish / hardswish go through ddpm_gn_act_backward)", act);
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(N * P)), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, (bf16*)dx, part, HW,
                        C, P, act);
     return ddpm_check_launch("act_backward");
@@ -527,6 +527,18 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
                                                            const ddpm_reduce_entry* __restrict__ entries) {
     __shared__ float s[4][64];
     const ddpm_reduce_entry e = entries[blockIdx.y];
+    if (e.scalar) {                                     // a contiguous run -> one number (fixed order: deterministic)
+        if (blockIdx.x) return;
+        float acc = 0.f;
+        const float* p = src + e.src_off;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < e.rows; i += 256) acc += p[i];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) s[0][threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) dst[e.dst_off] += (s[0][0] + s[0][1]) + (s[0][2] + s[0][3]);
+        return;
+    }
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     if (blockIdx.x * 64 >= e.width) return;
     const int rl = threadIdx.x >> 6;

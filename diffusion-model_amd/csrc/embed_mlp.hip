@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdArgs a) {
 static int embed_check(int N, int t_dim, int act, int nmlp, const int* C) {
     DDPM_REQUIRE(N > 0 && nmlp > 0 && nmlp <= DDPM_EMBED_MAX, "embed: need 1..%d MLPs and a positive batch", DDPM_EMBED_MAX);
     DDPM_REQUIRE(t_dim == EMB_T, "embed: the fused kernels are built for t_embed_dim %d, got %d", EMB_T, t_dim);
-    DDPM_REQUIRE(act >= ACT_NONE && act <= ACT_LAST, "embed: bad activation %d", act);
+    DDPM_REQUIRE(act >= ACT_NONE && act <= ACT_LAST && !ACT_HAS_BETA(act), "embed: bad activation %d (swish / hardswish are not fused here)", act);
     for (int i = 0; i < nmlp; ++i) DDPM_REQUIRE(C[i] >= 32 && C[i] <= 512 && C[i] % 32 == 0, "embed: width %d must be a multiple of 32 in 32..512", C[i]);
     return DDPM_OK;
 }

@@ -30,6 +30,8 @@ struct GnArgs {
     int N, HW, C, G, SC;           // SC = slab width (channels)
     int act;
     float eps;
+    const float* act_beta;         // the activation's learnable scalar (swish / hardswish), else unused
+    float* dbeta_part;             // backward, swish / hardswish: [N][C] per image and channel sums of dy * mask * d act / d scalar
     float* scratch;                // split path: partial sums of the pixel splits
     int P, rows_per_split;         // split path: pixel splits per (image, slab) and pixels per split
 };
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
 
     constexpr bool CACHED = NV > 0;
     constexpr int GN_NV = NV > 0 ? NV : 1;
+    const float bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
     // per-channel affine parameters are fetched up front so their latency overlaps the slab loads
     float gam[8], bet[8];
 #pragma unroll
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     auto finish = [&](const bf16x8& v, long long e) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act);
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act, bsc);
         if (a.mask) {
             const unsigned m = a.mask[e >> 3];
 #pragma unroll
@@ -193,15 +196,22 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
             ga[j] = 1.f; be[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f;
         }
     }
-    // g and xhat of one vector
-    auto gx = [&](const bf16x8& xv, const bf16x8& dv, long long e, float (&g)[8], float (&xh)[8]) {
+    const bool hb = ACT_HAS_BETA(a.act);
+    const float bsc = hb ? *a.act_beta : 1.f;
+    float ab[8];                                  // swish / hardswish: per-channel sums for the scalar's gradient
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ab[j] = 0.f;
+    // g and xhat of one vector; acc: also add this vector's terms of the activation scalar's gradient
+    auto gx = [&](const bf16x8& xv, const bf16x8& dv, long long e, float (&g)[8], float (&xh)[8], bool acc) {
         const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
         const float ms = a.mask ? a.mask_scale : 1.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             xh[j] = ((float)xv[j] - mean[j]) * rstd[j];
-            const float gg = (float)dv[j] * act_bwd(xh[j] * ga[j] + be[j], a.act) * ms;
+            const float z = xh[j] * ga[j] + be[j];
+            const float gg = (float)dv[j] * act_bwd(z, a.act, bsc) * ms;
             g[j] = (m >> j) & 1 ? gg : 0.f;
+            if (hb && acc) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, bsc) * ms : 0.f;
         }
     };
     // cached path: x stays in registers as bf16, the activation-gradient term g as fp32 (so exp/erf run once)
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) gc[k][j] = 0.f;
             if (p < a.HW) {
-                gx(xc[k], dc[k], base + (long long)p * a.C, gc[k], xh);
+                gx(xc[k], dc[k], base + (long long)p * a.C, gc[k], xh, true);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { a1[j] += gc[k][j]; a2[j] += gc[k][j] * xh[j]; }
             }
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
         for (int p = prow; p < a.HW; p += pstep) {
             const long long e = base + (long long)p * a.C;
             float g[8], xh[8];
-            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh);
+            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh, true);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
         }
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
         for (int p = prow; p < a.HW; p += pstep) {
             const long long e = base + (long long)p * a.C;
             float g[8], xh[8];
-            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh);
+            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh, a.G == 0);   // without a norm this is the only pass
             bf16x8 w;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -317,6 +327,13 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
     if (tid < vps) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) a.part[((long long)n * 3 + 2) * a.C + c0 + tid * 8 + j] = db[j];
+    }
+    if (hb) {
+        block_reduce_cols<THREADS>(ab, vps, s_red, tid);
+        if (tid < vps) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a.dbeta_part[(long long)n * a.C + c0 + tid * 8 + j] = ab[j];
+        }
     }
 }
 
@@ -405,13 +422,14 @@ __global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a
         }
     }
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
+    const float bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
 #pragma unroll 2
     for (int r = r0 + prow; r < r1; r += pstep) {
         const long long e = base + (long long)r * a.C;
         const bf16x8 v = *(const bf16x8*)(a.x + e);
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act);
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act, bsc);
         if (a.mask) {
             const unsigned m = a.mask[e >> 3];
 #pragma unroll
@@ -432,9 +450,11 @@ __global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a
 // g = dy * mask * act'(z) and xhat of one vector (shared by the two backward split kernels)
 struct GnBwdLane {
     float ga[8], be[8], mean[8], rstd[8];
+    float bsc;                                    // the activation's scalar (1 for the parameter-free ones)
 };
 __device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, GnBwdLane& L) {
     const int cpg = a.G > 0 ? a.C / a.G : 1;
+    L.bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (a.G > 0) {
@@ -447,7 +467,9 @@ __device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, 
         }
     }
 }
-__device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, long long e, float (&g)[8], float (&xh)[8], float (&xf)[8]) {
+// ab != nullptr: also adds this vector's terms of the activation scalar's gradient
+__device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, long long e, float (&g)[8], float (&xh)[8], float (&xf)[8],
+                                          float* ab = nullptr) {
     const bf16x8 xv = *(const bf16x8*)(a.x + e), dv = *(const bf16x8*)(a.dy + e);
     const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
     const float ms = a.mask ? a.mask_scale : 1.f;
@@ -455,12 +477,17 @@ __device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, l
     for (int j = 0; j < 8; ++j) {
         xf[j] = (float)xv[j];
         xh[j] = (xf[j] - L.mean[j]) * L.rstd[j];
-        const float gg = (float)dv[j] * act_bwd(xh[j] * L.ga[j] + L.be[j], a.act) * ms;
+        const float z = xh[j] * L.ga[j] + L.be[j];
+        const float gg = (float)dv[j] * act_bwd(z, a.act, L.bsc) * ms;
         g[j] = (m >> j) & 1 ? gg : 0.f;
+        if (ab) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
     }
 }
 
-// scratch layout (backward): [N][P][3][C] = per split and channel: sum g, sum g*xhat, sum x
+// rows of the backward scratch per (image, split): sum g, sum g*xhat, sum x and, for swish / hardswish, the scalar-gradient terms
+__device__ __host__ __forceinline__ int gn_bwd_rows(int act) { return ACT_HAS_BETA(act) ? 4 : 3; }
+
+// scratch layout (backward): [N][P][rows][C] per split and channel
 __global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a) {
     __shared__ float s_red[(GS_T / 64) * 64 < 128 ? 128 : (GS_T / 64) * 64];
     const int tid = threadIdx.x;
@@ -472,24 +499,31 @@ __global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a)
     const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
     GnBwdLane L;
     gn_bwd_lane_init(a, n, c0 + cv * 8, L);
-    float a1[8], a2[8], sx[8];
+    float a1[8], a2[8], sx[8], ab[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = sx[j] = 0.f;
+    for (int j = 0; j < 8; ++j) a1[j] = a2[j] = sx[j] = ab[j] = 0.f;
+    const bool hb = ACT_HAS_BETA(a.act);
+    const int R = gn_bwd_rows(a.act);
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
 #pragma unroll 2
     for (int r = r0 + prow; r < r1; r += pstep) {
         float g[8], xh[8], xf[8];
-        gn_bwd_gx(a, L, base + (long long)r * a.C, g, xh, xf);
+        gn_bwd_gx(a, L, base + (long long)r * a.C, g, xh, xf, hb ? ab : nullptr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
     }
     block_reduce_cols<GS_T>(a1, vps, s_red, tid);
     block_reduce_cols<GS_T>(a2, vps, s_red, tid);
     block_reduce_cols<GS_T>(sx, vps, s_red, tid);
+    if (hb) block_reduce_cols<GS_T>(ab, vps, s_red, tid);
     if (tid < vps) {
-        float* o = a.scratch + (((long long)n * a.P + p) * 3) * a.C + c0 + tid * 8;
+        float* o = a.scratch + (((long long)n * a.P + p) * R) * a.C + c0 + tid * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o[j] = a1[j]; o[a.C + j] = a2[j]; o[2 * a.C + j] = sx[j]; }
+        if (hb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[3 * a.C + j] = ab[j];
+        }
     }
 }
 
@@ -504,10 +538,16 @@ __global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a
     const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
     const int cpg = a.G > 0 ? a.C / a.G : 1;
     if (tid < a.SC) {                                 // per-channel totals: the P partials in a fixed order
-        const float* in = a.scratch + ((long long)n * a.P * 3) * a.C + c0 + tid;
+        const int R = gn_bwd_rows(a.act);
+        const float* in = a.scratch + ((long long)n * a.P * R) * a.C + c0 + tid;
         float u = 0.f, v = 0.f, w = 0.f;
-        for (int q = 0; q < a.P; ++q) { u += in[(q * 3 + 0) * a.C]; v += in[(q * 3 + 1) * a.C]; w += in[(q * 3 + 2) * a.C]; }
+        for (int q = 0; q < a.P; ++q) { u += in[(q * R + 0) * a.C]; v += in[(q * R + 1) * a.C]; w += in[(q * R + 2) * a.C]; }
         s_a1[tid] = u; s_a2[tid] = v; s_sx[tid] = w;
+        if (R == 4 && p == 0) {
+            float t = 0.f;
+            for (int q = 0; q < a.P; ++q) t += in[(q * R + 3) * a.C];
+            a.dbeta_part[(long long)n * a.C + c0 + tid] = t;
+        }
     }
     __syncthreads();
     if (a.G > 0) {
@@ -594,6 +634,9 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     a.mask_scale = d->mask_scale; a.y = (bf16*)d->y; a.stats = d->stats; a.dy = (const bf16*)d->dy; a.part = d->part;
     a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.SC = sc; a.act = d->act;
     a.eps = d->eps;
+    DDPM_REQUIRE(d->act >= 0 && d->act <= ACT_LAST, "%s: unknown activation %d", what, d->act);
+    DDPM_REQUIRE(!ACT_HAS_BETA(d->act) || d->act_beta, "%s: swish / hardswish need their scalar (act_beta)", what);
+    a.act_beta = d->act_beta; a.dbeta_part = d->dbeta_part;
     a.scratch = d->scratch; a.P = 0; a.rows_per_split = 0;
     return DDPM_OK;
 }
@@ -602,7 +645,7 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
 static long long gn_scratch_need(const GnArgs& a, bool backward) {
     const int P = gn_splits(a);
     if (!P) return 0;
-    return backward ? (long long)a.N * P * 3 * a.C : (long long)a.N * (a.G > 0 ? a.G : 0) * P * 2;
+    return backward ? (long long)a.N * P * gn_bwd_rows(a.act) * a.C : (long long)a.N * (a.G > 0 ? a.G : 0) * P * 2;
 }
 
 extern "C" int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward) {
@@ -611,6 +654,7 @@ extern "C" int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward) {
     if (!t.x) t.x = (const void*)16;                  // sizing query: pointers are not dereferenced
     if (!t.y) t.y = (void*)16;
     if (t.G > 0) { if (!t.gamma) t.gamma = (const float*)16; if (!t.beta) t.beta = (const float*)16; if (!t.stats) t.stats = (float*)16; }
+    if (ACT_HAS_BETA(t.act) && !t.act_beta) t.act_beta = (const float*)16;
     if (gn_prepare(a, &t, "gn_scratch_floats")) return -1;
     const long long need = gn_scratch_need(a, backward != 0);
     return need > 0 ? need : (gn_splits(a) ? 1 : 0);   // activation-only forward needs no partial sums but still takes the split path
@@ -660,6 +704,7 @@ extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_
     if (int rc = gn_prepare(a, d, "gn_backward")) return rc;
     DDPM_REQUIRE(d->dy, "gn_backward: null dy");
     DDPM_REQUIRE(a.part, "gn_backward: partial-sum workspace required");
+    DDPM_REQUIRE(!ACT_HAS_BETA(a.act) || a.dbeta_part, "gn_backward: swish / hardswish need the [N][C] workspace of the scalar's gradient (dbeta_part)");
     if (gn_use_split(a, d, true)) {
         const int units = a.N * (a.C / a.SC) * a.P;
         hipLaunchKernelGGL(gn_bwd_split_sums_kernel, dim3(units), dim3(GS_T), 0, stream, a);

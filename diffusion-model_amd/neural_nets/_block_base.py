@@ -12,7 +12,7 @@ from torch import Tensor, nn
 from ..runtime import hip
 from ..runtime.engine import UNetEngine
 from ..utils.initializers import get_initializer
-from .activations import activation_code
+from .activations import activation_code, has_scalar
 
 W_INIT, ONES, ZEROS, LINEAR_BIAS_DEFAULT = range(4)
 BF16 = torch.bfloat16
@@ -27,6 +27,8 @@ class BlockSpec:
         self.expand = expand_factor
         self.drop_p = float(drop_p)
         self.act = hip.ACT[activation]
+        self.act_name = activation
+        self.act_scalar = self.act in hip.ACT_WITH_SCALAR
         self.groups = 4 * int(base_groups_norm)
 
 
@@ -158,10 +160,16 @@ def norm_entries(name: str, c: int):
     return [(name + ".weight", (c,), ONES), (name + ".bias", (c,), ZEROS)]
 
 
-def sir_entries(pre: str, c: int, expand) -> list:
+def act_entries(site: str, activation: str) -> list:
+    """the activation module at `site`: swish / hardswish own one 0-dim parameter `beta`, initialised to 1
+    (neural_nets/activations.py:40,60 of the reference); the others own nothing"""
+    return [(site + ".beta", (), ONES)] if has_scalar(activation) else []
+
+
+def sir_entries(pre: str, c: int, expand, activation: str = "gelu") -> list:
     e = int(expand * c)
-    return (conv_entries(pre + "expansion.1", e, c, 1) + norm_entries(pre + "expansion.2", e) +
-            conv_entries(pre + "depthwise.1", e, 1, 3) + norm_entries(pre + "depthwise.2", e) +
+    return (conv_entries(pre + "expansion.1", e, c, 1) + norm_entries(pre + "expansion.2", e) + act_entries(pre + "expansion.3", activation) +
+            conv_entries(pre + "depthwise.1", e, 1, 3) + norm_entries(pre + "depthwise.2", e) + act_entries(pre + "depthwise.3", activation) +
             conv_entries(pre + "projection.1", c, e, 1) + norm_entries(pre + "projection.2", c))
 
 

@@ -1,7 +1,8 @@
 """SeparableInvertResidual behind the reference's constructor (neural_nets/conv_block.py:19-136 there): the
 MobileNetV2-style block dropout -> 1x1 expansion -> GroupNorm -> act -> dropout -> depthwise 3x3 -> GroupNorm -> act ->
 dropout -> 1x1 projection -> GroupNorm (+ input), executed by one fused HIP kernel per direction where the shape allows
-and by the per-unit kernels otherwise.  state_dict keys: expansion.{1,2}.*, depthwise.{1,2}.*, projection.{1,2}.*."""
+and by the per-unit kernels otherwise.  state_dict keys: expansion.{1,2}.*, depthwise.{1,2}.*, projection.{1,2}.*, plus
+expansion.3.beta and depthwise.3.beta when the activation is swish or hardswish (the reference block's default is swish)."""
 from __future__ import annotations
 
 from ..runtime import hip
@@ -22,7 +23,7 @@ class SeparableInvertResidual(BlockModule):
         self.in_channels, self.expand_factor = in_channels, expand_factor
         spec = BlockSpec({"expansion.1": hip.CONV_1X1, "projection.1": hip.CONV_1X1}, ["depthwise.1"], expand_factor, drop_p, activation,
                          base_groups_norm)
-        self._build(sir_entries("", in_channels, expand_factor), spec, initializer, device, dtype)
+        self._build(sir_entries("", in_channels, expand_factor, activation), spec, initializer, device, dtype)
 
     def _program(self, units, inputs):
         return units.sir("", inputs[0])

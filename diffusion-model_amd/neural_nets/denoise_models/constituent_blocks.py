@@ -18,8 +18,8 @@ import math
 
 from ...runtime import hip
 from ...runtime.engine import attention_convs
-from .._block_base import (ZEROS, BF16, LINEAR_BIAS_DEFAULT, ONES, W_INIT, BlockModule, BlockSpec, check_activation, conv_entries, norm_entries,
-                           sir_entries)
+from .._block_base import (ZEROS, BF16, LINEAR_BIAS_DEFAULT, ONES, W_INIT, BlockModule, BlockSpec, act_entries, check_activation, conv_entries,
+                           norm_entries, sir_entries)
 
 
 def _common(kwargs):
@@ -36,8 +36,9 @@ class DownBlock(BlockModule):
             raise ValueError(f"channels must be multiples of 16 (in) / 32 (out) for the MFMA kernels, got {in_channels} -> {out_channels}")
         self.expand = expand
         co = out_channels
-        table = (conv_entries("layers.0.0", co, in_channels, 3) + norm_entries("layers.0.1", co) + sir_entries("layers.1.", co, expand) +
-                 sir_entries("layers.2.", co, expand) + conv_entries("layers.3.0", co, co, 3) + norm_entries("layers.3.1", co))
+        table = (conv_entries("layers.0.0", co, in_channels, 3) + norm_entries("layers.0.1", co) + act_entries("layers.0.2", act) +
+                 sir_entries("layers.1.", co, expand, act) + sir_entries("layers.2.", co, expand, act) +
+                 conv_entries("layers.3.0", co, co, 3) + norm_entries("layers.3.1", co) + act_entries("layers.3.2", act))
         convs = {"layers.0.0": hip.CONV_3X3_S2, "layers.1.expansion.1": hip.CONV_1X1, "layers.1.projection.1": hip.CONV_1X1,
                  "layers.2.expansion.1": hip.CONV_1X1, "layers.2.projection.1": hip.CONV_1X1, "layers.3.0": hip.CONV_3X3_S1}
         self._build(table, BlockSpec(convs, ["layers.1.depthwise.1", "layers.2.depthwise.1"], expand, drop_p, act, bgn), init, device, dtype)
@@ -69,9 +70,10 @@ class UpBlock(BlockModule):
             raise ValueError(f"channels must be multiples of 32 for the MFMA kernels, got {in_channels} -> {out_channels}")
         self.expand, self.cin, self.cout = expand, in_channels, out_channels
         ci, co = in_channels, out_channels
-        table = (conv_entries("layers.0.0", ci, 2 * ci, 3) + norm_entries("layers.0.1", ci) + sir_entries("layers.1.", ci, expand) +
+        table = (conv_entries("layers.0.0", ci, 2 * ci, 3) + norm_entries("layers.0.1", ci) + act_entries("layers.0.2", act) +
+                 sir_entries("layers.1.", ci, expand, act) +
                  [("layers.2.0.weight", (ci, co, 2, 2), W_INIT), ("layers.2.0.bias", (co,), ONES)] + norm_entries("layers.2.1", co) +
-                 sir_entries("layers.3.", co, expand) + sir_entries("layers.4.", co, expand))
+                 act_entries("layers.2.2", act) + sir_entries("layers.3.", co, expand, act) + sir_entries("layers.4.", co, expand, act))
         convs = {"layers.0.0": hip.CONV_3X3_S1, "layers.2.0": hip.CONVT_2X2_S2}
         for i in (1, 3, 4):
             convs[f"layers.{i}.expansion.1"] = hip.CONV_1X1
@@ -102,7 +104,7 @@ def _linear_default(fan_in: int):
     return lambda t: nn.init.uniform_(t, -bound, bound)
 
 
-def conditional_entries(pre: str, c: int, depth: int, kdim: int):
+def conditional_entries(pre: str, c: int, depth: int, kdim: int, activation: str = "gelu"):
     """Parameters of a ConditionalModule in the reference's registration order (constituent_blocks.py:357-399; inside
     nn.MultiheadAttention: in_proj_weight or q/k/v_proj_weight, in_proj_bias, out_proj) with torch's default initialisers
     (xavier_uniform for the input projections, zero attention biases, nn.Linear defaults elsewhere)."""
@@ -121,6 +123,8 @@ def conditional_entries(pre: str, c: int, depth: int, kdim: int):
         out += [(f"{pre}linears.{i}.weight", (c, c), _linear_default(c)), (f"{pre}linears.{i}.bias", (c,), _linear_default(c))]
     for i in range(depth):
         out += norm_entries(f"{pre}linear_norms.{i}", c)
+    for i in range(depth):                              # self.activations is registered last (:398-399)
+        out += act_entries(f"{pre}activations.{i}", activation)
     return out
 
 
@@ -143,7 +147,7 @@ class ConditionalModule(BlockModule):
         attention_convs(convs, aliases, "", c, kdim, self.depth)
         spec = BlockSpec(convs, [], 2, drop_p, activation, 4)
         spec.aliases = aliases
-        self._build(conditional_entries("", c, self.depth, kdim), spec, "normal", device, dtype)
+        self._build(conditional_entries("", c, self.depth, kdim, activation), spec, "normal", device, dtype)
 
     def _program(self, u, inputs):
         cond = inputs[1] if len(inputs) > 1 else None
@@ -197,8 +201,9 @@ class EmbedBlock(BlockModule):
         if input_dim % 16 or embed_dim % 32:
             raise ValueError(f"input_dim must be a multiple of 16 and embed_dim of 32 for the MFMA kernels, got {input_dim}, {embed_dim}")
         self.input_dim, self.embed_dim = input_dim, embed_dim
-        table = [("layers.0.weight", (2 * embed_dim, input_dim), W_INIT), ("layers.0.bias", (2 * embed_dim,), LINEAR_BIAS_DEFAULT),
-                 ("layers.2.weight", (embed_dim, 2 * embed_dim), W_INIT), ("layers.2.bias", (embed_dim,), ONES)]
+        table = ([("layers.0.weight", (2 * embed_dim, input_dim), W_INIT), ("layers.0.bias", (2 * embed_dim,), LINEAR_BIAS_DEFAULT)] +
+                 act_entries("layers.1", activation) +
+                 [("layers.2.weight", (embed_dim, 2 * embed_dim), W_INIT), ("layers.2.bias", (embed_dim,), ONES)])
         spec = BlockSpec({"layers.0": hip.CONV_1X1, "layers.2": hip.CONV_1X1}, [], 2, 0.0, activation, 4)
         self._build(table, spec, initializer, device, dtype, linear_fan_in=input_dim)
         # second Linear's default weight init is replaced by the initializer, its bias by ones (constituent_blocks.py:321-324)

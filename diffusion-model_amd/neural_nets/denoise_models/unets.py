@@ -1,7 +1,8 @@
 """BaseUNet: the denoiser backbone behind the reference's constructor and forward signature
 (neural_nets/denoise_models/unets.py:243-273 there), executed by the HIP engine.
 
-The module owns ordinary fp32 nn.Parameters with exactly the reference's 350 state_dict keys, shapes and
+The module owns ordinary fp32 nn.Parameters with exactly the reference's state_dict keys (350 for the default 4-stage
+network; swish / hardswish add one 0-dim `beta` per activation module), shapes and
 registration order, so checkpoints, optimizers, EMA copies and DDP wrappers see the same object they would see
 with the reference class.  The sub-modules are plain parameter containers: all arithmetic happens in
 runtime/engine.py, entered through one autograd Function.
@@ -41,6 +42,11 @@ def parameter_table(spec: UNetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
     out: List[Tuple[str, Tuple[int, ...], int]] = []
     st, te, ex = spec.stages, spec.t_dim, spec.expand
 
+    def actp(site):
+        """the activation module at `site`: swish / hardswish own a 0-dim `beta` = 1 (activations.py:40,60 there)"""
+        if spec.act_scalar:
+            out.append((site + ".beta", (), ONES))
+
     def conv(name, co, ci, k, bias_rule=ONES):
         out.append((name + ".weight", (co, ci, k, k), W_INIT))
         out.append((name + ".bias", (co,), bias_rule))
@@ -51,13 +57,14 @@ def parameter_table(spec: UNetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
 
     def sir(pre, c):
         e = int(ex * c)
-        conv(pre + "expansion.1", e, c, 1); norm(pre + "expansion.2", e)
-        conv(pre + "depthwise.1", e, 1, 3); norm(pre + "depthwise.2", e)
+        conv(pre + "expansion.1", e, c, 1); norm(pre + "expansion.2", e); actp(pre + "expansion.3")
+        conv(pre + "depthwise.1", e, 1, 3); norm(pre + "depthwise.2", e); actp(pre + "depthwise.3")
         conv(pre + "projection.1", c, e, 1); norm(pre + "projection.2", c)
 
     def embed(pre, c, rule):
         out.append((pre + "layers.0.weight", (2 * c, te), rule))
         out.append((pre + "layers.0.bias", (2 * c,), LINEAR_BIAS_DEFAULT))
+        actp(pre + "layers.1")
         out.append((pre + "layers.2.weight", (c, 2 * c), rule))
         out.append((pre + "layers.2.bias", (c,), ONES))
 
@@ -65,42 +72,43 @@ def parameter_table(spec: UNetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
         # torch's default initialisers; the table's ZEROS differs from the block modules' constant, so map it here
         from .constituent_blocks import conditional_entries
         from .._block_base import ZEROS as BLOCK_ZEROS, ONES as BLOCK_ONES
-        for name, shape, rule in conditional_entries(pre, c, spec.attn_depth, c):
+        for name, shape, rule in conditional_entries(pre, c, spec.attn_depth, c, spec.act_name):
             out.append((name, shape, rule if callable(rule) else {BLOCK_ZEROS: ZEROS, BLOCK_ONES: ONES}[rule]))
 
     e = "encoder."
-    conv(e + "stem_layers.0", st[0], spec.img_channels, 3)
+    conv(e + "stem_layers.0", st[0], spec.img_channels, 3); actp(e + "stem_layers.1")
     ins = [st[0]] + st[:-1]
     for i, (ci, co) in enumerate(zip(ins, st)):
         b = f"{e}layers.{i}.layers."
-        conv(b + "0.0", co, ci, 3); norm(b + "0.1", co)
+        conv(b + "0.0", co, ci, 3); norm(b + "0.1", co); actp(b + "0.2")
         k = 1
         if i in spec.attn_stages:
             attention(b + "1.", co)
             k = 2
         sir(f"{b}{k}.", co); sir(f"{b}{k + 1}.", co)
-        conv(f"{b}{k + 2}.0", co, co, 3); norm(f"{b}{k + 2}.1", co)
+        conv(f"{b}{k + 2}.0", co, co, 3); norm(f"{b}{k + 2}.1", co); actp(f"{b}{k + 2}.2")
     for i, ci in enumerate(ins):
         embed(f"{e}t_embeddings.{i}.", ci, W_INIT)
-    conv(e + "latent_layers.0", spec.latent_dim, st[-1], 3); norm(e + "latent_layers.1", spec.latent_dim)
+    conv(e + "latent_layers.0", spec.latent_dim, st[-1], 3); norm(e + "latent_layers.1", spec.latent_dim); actp(e + "latent_layers.2")
 
     d = "decoder."
     rs = st[::-1]
-    conv(d + "decoder_input_layers.0", rs[0], spec.latent_dim, 3); norm(d + "decoder_input_layers.1", rs[0])
+    conv(d + "decoder_input_layers.0", rs[0], spec.latent_dim, 3); norm(d + "decoder_input_layers.1", rs[0]); actp(d + "decoder_input_layers.2")
     outs = rs[1:] + [rs[-1]]
     for i, (ci, co) in enumerate(zip(rs, outs)):
         b = f"{d}layers.{i}.layers."
-        conv(b + "0.0", ci, 2 * ci, 3); norm(b + "0.1", ci)
+        conv(b + "0.0", ci, 2 * ci, 3); norm(b + "0.1", ci); actp(b + "0.2")
         k = 1
         if len(st) - 1 - i in spec.attn_stages:
             attention(b + "1.", ci)
             k = 2
         sir(f"{b}{k}.", ci)
         out.append((f"{b}{k + 1}.0.weight", (ci, co, 2, 2), W_INIT)); out.append((f"{b}{k + 1}.0.bias", (co,), ONES)); norm(f"{b}{k + 1}.1", co)
+        actp(f"{b}{k + 1}.2")
         sir(f"{b}{k + 2}.", co); sir(f"{b}{k + 3}.", co)
     for i, ci in enumerate(rs):
         embed(f"{d}t_embeddings.{i}.", ci, W_INIT_EMBED_DEC)
-    conv(d + "out_layers.0", rs[-1], rs[-1], 3)
+    conv(d + "out_layers.0", rs[-1], rs[-1], 3); actp(d + "out_layers.1")
     conv(d + "out_layers.2", spec.img_channels, rs[-1], 3, bias_rule=ZEROS)
     return out
 

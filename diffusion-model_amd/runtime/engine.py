@@ -82,6 +82,8 @@ class UNetSpec:
         self.drop_p = float(drop_p)
         self.t_dim = int(t_embed_dim)
         self.act = hip.ACT[activation]
+        self.act_name = activation
+        self.act_scalar = self.act in hip.ACT_WITH_SCALAR        # swish / hardswish: every activation module owns a learnable scalar
         self.groups = 4 * int(base_groups_norm)
         self.latent_groups = 8 * int(base_groups_norm)
         self.time_norm = float(time_norm)
@@ -303,6 +305,23 @@ class UNetEngine:
                 part_ws[0] = torch.empty(self._reduce_tables[rkey][3], device=dev, dtype=torch.float32)
             return part_ws[0][off:off + numel], off
 
+        has_scalar = bool(getattr(sp, "act_scalar", False))
+
+        def act_site(last: str) -> str:
+            """state_dict prefix of the activation module that follows module `last` in its nn.Sequential ('x.1' -> 'x.2')"""
+            head, _, idx = last.rpartition(".")
+            return f"{head}.{int(idx) + 1}" if head else str(int(idx) + 1)
+
+        def act_scalar(site: Optional[str], act: int) -> Optional[Tensor]:
+            """the learnable scalar of a swish / hardswish module (None for the parameter-free activations)"""
+            return P[site + ".beta"] if (has_scalar and act in hip.ACT_WITH_SCALAR) else None
+
+        def scalar_partials(site: str, numel: int) -> Tensor:
+            """workspace for the partial sums of an activation scalar's gradient; folded to one number with all the others"""
+            buf, off = part_alloc(numel)
+            part_entries.append((off, G.offset(site + ".beta"), numel, 0, 1))          # row stride 0 marks a scalar fold
+            return buf
+
         def gn_partials(c: int, norm: Optional[str], conv_name: Optional[str]) -> Tensor:
             buf, off = part_alloc(n * 3 * c)
             if norm:
@@ -357,18 +376,20 @@ class UNetEngine:
             wf = wc.fwd[name]
             bias = P[name + ".bias"]
             cout = bias.shape[0]
-            if norm is None and tape is None and res is None and out_mask is None:
+            site = act_site(norm or name)
+            bsc = act_scalar(site, act)           # swish / hardswish: applied by the GroupNorm/activation kernels only
+            if bsc is None and norm is None and tape is None and res is None and out_mask is None:
                 # inference, no normalisation: the activation runs in the convolution's epilogue (no pre-activation is kept)
                 return Var(ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                             in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act=act, c0_used=c0_used))
             gamma = P[norm + ".weight"] if norm else None
             beta = P[norm + ".bias"] if norm else None
-            if norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
+            if bsc is None and norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
                 # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
                 raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                                  in_add=None if in_add is None else in_add.v,
                                                  gn=(gamma, beta, groups, act, None if res is None else res.v))
-            elif norm is None and res is None and out_mask is None and cout % 8 == 0 and x0.v.shape[1] > 4:
+            elif bsc is None and norm is None and res is None and out_mask is None and cout % 8 == 0 and x0.v.shape[1] > 4:
                 # no normalisation: the activated tensor is a second result of the convolution's launch (the pre-activation
                 # stays for the backward pass)
                 raw, y = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
@@ -379,7 +400,7 @@ class UNetEngine:
                 raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                        in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, c0_used=c0_used)
                 y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
-                                              mask=out_mask, mask_scale=mscale)
+                                              mask=out_mask, mask_scale=mscale, act_beta=bsc)
             out = Var(y)
             if tape is not None:
                 tape.append(conv_bwd(name, x0, x1, in_add, in_mask, raw, out, stats, norm, groups, act, res, out_mask))
@@ -391,6 +412,8 @@ class UNetEngine:
             cout = P[name + ".bias"].shape[0]
             gamma = P[norm + ".weight"] if norm else None
             beta = P[norm + ".bias"] if norm else None
+            site = act_site(norm or name)
+            bsc = act_scalar(site, act)
 
             def bwd():
                 dy = out.g
@@ -400,7 +423,7 @@ class UNetEngine:
                 wd = wc.dgrad[name]
                 c0 = x0.v.shape[3]
                 dk = pack.DGRAD_KIND[kind]
-                if (norm and out_mask is None and x0.need_grad
+                if (bsc is None and norm and out_mask is None and x0.need_grad
                         and ops.conv_gnb_fusable(dk, dy, c0, groups, masked=in_mask is not None)):
                     # the GroupNorm / activation backward runs in the loader of the data-gradient convolution (its tile
                     # holds whole images and whole groups), which also writes the raw gradient the weight-gradient launch
@@ -418,7 +441,7 @@ class UNetEngine:
                         c1 = x1.v.shape[3]
                         x1.g = ops.conv_forward(dk, draw, wd, None, c1, res=x1.g, row0=c0, rows=c1)
                     return
-                splits = ops.act_backward_splits(raw) if (norm is None and out_mask is None) else 0
+                splits = ops.act_backward_splits(raw) if (bsc is None and norm is None and out_mask is None) else 0
                 if splits:
                     # bare activation: a streaming kernel with many workgroups per image; its partial bias-gradient rows
                     # are folded with all the others
@@ -427,7 +450,8 @@ class UNetEngine:
                     draw = ops.act_backward(raw, dy, act, buf, splits)
                 else:
                     draw = ops.gn_act_backward(raw, dy, gamma, beta, groups if norm else 0, act, stats,
-                                               gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale)
+                                               gn_partials(cout, norm, name), mask=out_mask, mask_scale=mscale, act_beta=bsc,
+                                               dbeta_part=None if bsc is None else scalar_partials(site, n * cout))
                 out.g = None
                 wgrad(kind, x0.v, draw, cout, name, x1=None if x1 is None else x1.v,
                       in_add=None if in_add is None else in_add.v, in_mask=in_mask)
@@ -449,7 +473,8 @@ class UNetEngine:
             name, norm = pre + "depthwise.1", pre + "depthwise.2"
             raw = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"])
             gamma, beta = P[norm + ".weight"], P[norm + ".bias"]
-            y, stats = ops.gn_act_forward(raw, gamma, beta, sp.groups, sp.act, mask=out_mask, mask_scale=mscale)
+            y, stats = ops.gn_act_forward(raw, gamma, beta, sp.groups, sp.act, mask=out_mask, mask_scale=mscale,
+                                          act_beta=act_scalar(act_site(norm), sp.act))
             out = Var(y)
             if tape is not None:
                 tape.append(dw_bwd(pre, xin, raw, out, stats, out_mask))
@@ -461,8 +486,10 @@ class UNetEngine:
 
             def bwd():
                 cch = raw.shape[3]
+                bsc = act_scalar(act_site(norm), sp.act)
                 draw = ops.gn_act_backward(raw, out.g, gamma, beta, sp.groups, sp.act, stats, gn_partials(cch, norm, None),
-                                           mask=out_mask, mask_scale=mscale)
+                                           mask=out_mask, mask_scale=mscale, act_beta=bsc,
+                                           dbeta_part=None if bsc is None else scalar_partials(act_site(norm), n * cch))
                 out.g = None
                 nb = ops.dwconv3x3_wgrad_blocks(*xin.v.shape)
                 buf, off = part_alloc(nb * 10 * cch)
@@ -586,12 +613,15 @@ class UNetEngine:
                 r_raw = ops.conv_forward(K11, o, wc.fwd[m + "out_proj"], P[m + "out_proj.bias"], c, res=x_in.v)
                 r, st1 = ops.sample_norm_forward(r_raw, None, 0, P[mn + ".weight"], P[mn + ".bias"])
                 h_raw = ops.conv_forward(K11, r, wc.fwd[lin], P[lin + ".bias"], c)
-                y, st2 = ops.sample_norm_forward(h_raw, r, sp.act, P[ln + ".weight"], P[ln + ".bias"])
+                asite = f"{pre}activations.{i}"
+                y, st2 = ops.sample_norm_forward(h_raw, r, sp.act, P[ln + ".weight"], P[ln + ".bias"], act_beta=act_scalar(asite, sp.act))
                 out = Var(y)
                 if tape is not None:
                     def bwd(m=m, mn=mn, lin=lin, ln=ln, packed=packed, cnd=cnd, gb_in=gb_in, sid=sid, x_in=x_in, q=q, k=k, v=v, o=o, lse=lse,
-                            r_raw=r_raw, r=r, st1=st1, h_raw=h_raw, st2=st2, out=out):
-                        du2, da2 = ops.sample_norm_backward(h_raw, r, out.g, sp.act, P[ln + ".weight"], st2, gn_partials(c, ln, lin))
+                            r_raw=r_raw, r=r, st1=st1, h_raw=h_raw, st2=st2, out=out, asite=asite):
+                        bsc = act_scalar(asite, sp.act)
+                        du2, da2 = ops.sample_norm_backward(h_raw, r, out.g, sp.act, P[ln + ".weight"], st2, gn_partials(c, ln, lin),
+                                                            act_beta=bsc, dbeta_part=None if bsc is None else scalar_partials(asite, n))
                         out.g = None
                         wgrad(K11, r, da2, c, lin)
                         dr = ops.conv_forward(K11, da2, wc.dgrad[lin], None, c, res=du2)
@@ -716,7 +746,7 @@ class UNetEngine:
         temb_vars: Dict[str, Var] = {}
         embed_bwd_factory = None
         stage_seg: Dict[int, int] = {}                  # MLP index (encoder stages, then decoder stages) -> tape segment of its stage
-        if (self.fuse_embed and sp.t_dim == 32 and len(enames) <= hip.EMBED_MAX and all(32 <= c <= 512 and c % 32 == 0 for c in ewidths)
+        if (self.fuse_embed and not sp.act_scalar and sp.t_dim == 32 and len(enames) <= hip.EMBED_MAX and all(32 <= c <= 512 and c % 32 == 0 for c in ewidths)
                 and all(P[q + "layers.0.bias"].shape[0] == 2 * c for q, c in zip(enames, ewidths))):
             outs, esaved = ops.embed_forward(sin, [wc.fwd[q + "layers.0"] for q in enames], [P[q + "layers.0.bias"] for q in enames],
                                              [wc.fwd[q + "layers.2"] for q in enames], [P[q + "layers.2.bias"] for q in enames], sp.act,

@@ -13,7 +13,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libddpm_hip.so")
 
-ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5, "hardsigmoid": 6, "relu6": 7, "leaky_relu": 8, "selu": 9}
+ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5, "hardsigmoid": 6, "relu6": 7, "leaky_relu": 8, "selu": 9,
+       "swish": 10, "hardswish": 11}
+ACT_WITH_SCALAR = (10, 11)        # swish, hardswish: one learnable scalar per activation module
 CONV_3X3_S1, CONV_3X3_S2, CONV_1X1, CONVT_2X2_S2, DGRAD_3X3_S2, DGRAD_CONVT_2X2 = range(6)
 OUT_BF16_NHWC, OUT_F32_NCHW = 0, 1
 CONV_KERNEL_NAMES = {0: "conv_mfma_kernel", 1: "conv_mfma_kernel", 2: "conv_small_kernel", 3: "conv_thin_kernel", 4: "conv_img_kernel"}
@@ -42,6 +44,7 @@ class GnDesc(C.Structure):
         ("x", _vp), ("gamma", _vp), ("beta", _vp), ("res", _vp), ("mask", _vp), ("mask_scale", _f),
         ("y", _vp), ("stats", _vp), ("dy", _vp), ("part", _vp),
         ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f), ("scratch", _vp), ("scratch_floats", _i64),
+        ("act_beta", _vp), ("dbeta_part", _vp),
     ]
 
 
@@ -80,12 +83,13 @@ class AttnDesc(C.Structure):
 
 class SampleNormDesc(C.Structure):
     _fields_ = [("a", _vp), ("b", _vp), ("gamma", _vp), ("beta", _vp), ("y", _vp), ("stats", _vp), ("dy", _vp), ("du", _vp), ("da", _vp),
-                ("part", _vp), ("N", C.c_int32), ("S", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("eps", _f)]
+                ("part", _vp), ("N", C.c_int32), ("S", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("eps", _f),
+                ("act_beta", _vp), ("dbeta_part", _vp)]
 
 
 class ReduceEntry(C.Structure):
     _fields_ = [("src_off", _i64), ("dst_off", _i64), ("rows", C.c_int32), ("row_stride", C.c_int32), ("width", C.c_int32),
-                ("pad", C.c_int32)]
+                ("scalar", C.c_int32)]
 
 
 class RemapEntry(C.Structure):

@@ -183,8 +183,9 @@ def _gn_scratch(d, backward: int, device) -> Optional[Tensor]:
 
 def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int, *,
                    res: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
-                   stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5):
-    """x: NHWC bf16.  Returns (y, stats) with stats fp32 [N][G][2] (None when groups == 0)."""
+                   stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5, act_beta: Optional[Tensor] = None):
+    """x: NHWC bf16.  Returns (y, stats) with stats fp32 [N][G][2] (None when groups == 0).  act_beta: the activation's
+    learnable scalar (a device fp32 tensor with one element), required for swish / hardswish."""
     n, h, w, c = x.shape
     assert x.dtype == BF16 and x.is_contiguous()
     if out is None:
@@ -193,7 +194,7 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
         stats = torch.empty(n, groups, 2, device=x.device, dtype=torch.float32)
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=None, part=None, N=n, HW=h * w, C=c, G=groups,
-                   act=act, eps=eps)
+                   act=act, eps=eps, act_beta=_scalar_ptr(act, act_beta))
     scratch = _gn_scratch(d, 0, x.device)
     _launch("gn_fwd_split_kernel" if scratch is not None else "gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream()))
@@ -202,8 +203,10 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
 
 def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int,
                     stats: Optional[Tensor], part: Tensor, *, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
-                    out: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
-    """Returns dx.  part: fp32 [N][3][C] receives per-image partial sums (dgamma, dbeta, bias gradient)."""
+                    out: Optional[Tensor] = None, eps: float = 1e-5, act_beta: Optional[Tensor] = None,
+                    dbeta_part: Optional[Tensor] = None) -> Tensor:
+    """Returns dx.  part: fp32 [N][3][C] receives per-image partial sums (dgamma, dbeta, bias gradient).  swish / hardswish:
+    act_beta = the activation's scalar, dbeta_part = fp32 [N][C] that receives the partial sums of the scalar's gradient."""
     n, h, w, c = x.shape
     assert dy.shape == x.shape and dy.dtype == BF16 and dy.is_contiguous()
     assert part.dtype == torch.float32 and part.numel() == n * 3 * c
@@ -211,11 +214,21 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
         out = torch.empty_like(x)
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=None, mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), part=hip.ptr(part), N=n, HW=h * w, C=c, G=groups, act=act,
-                   eps=eps)
+                   eps=eps, act_beta=_scalar_ptr(act, act_beta), dbeta_part=hip.ptr(dbeta_part))
+    assert act not in hip.ACT_WITH_SCALAR or (dbeta_part is not None and dbeta_part.numel() == n * c and dbeta_part.dtype == torch.float32)
     scratch = _gn_scratch(d, 1, x.device)
     _launch("gn_bwd_split_kernel" if scratch is not None else "gn_bwd_kernel", lambda: (_nb(x, dy, mask, out, gamma, beta, stats, part), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream()))
     return out
+
+
+def _scalar_ptr(act: int, beta: Optional[Tensor]):
+    """device pointer of an activation's learnable scalar; swish / hardswish must bring one"""
+    if act not in hip.ACT_WITH_SCALAR:
+        return None
+    if beta is None or beta.numel() != 1 or beta.dtype != torch.float32 or not beta.is_cuda:
+        raise ValueError("swish / hardswish need their learnable scalar as a one-element fp32 device tensor")
+    return hip.ptr(beta)
 
 
 def act_backward_splits(x: Tensor) -> int:
@@ -396,20 +409,22 @@ def attention_backward(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, 
             lambda: hip.call("ddpm_attention_backward", C.byref(d), hip.stream()))
 
 
-def sample_norm_forward(a: Tensor, b: Optional[Tensor], act: int, gamma: Tensor, beta: Tensor, eps: float = 1e-5):
+def sample_norm_forward(a: Tensor, b: Optional[Tensor], act: int, gamma: Tensor, beta: Tensor, eps: float = 1e-5,
+                        act_beta: Optional[Tensor] = None):
     """y = GroupNorm(1, C)(act(a) + b) over each sample of bf16 [N,S,1,C].  Returns (y, stats fp32 [N,2])."""
     n, s, c = a.shape[0], a.numel() // (a.shape[0] * a.shape[-1]), a.shape[-1]
     assert a.dtype == BF16 and a.is_contiguous() and (b is None or (b.shape == a.shape and b.is_contiguous()))
     y = torch.empty_like(a)
     stats = torch.empty(n, 2, device=a.device, dtype=torch.float32)
     d = hip.SampleNormDesc(a=hip.ptr(a), b=hip.ptr(b), gamma=hip.ptr(gamma), beta=hip.ptr(beta), y=hip.ptr(y), stats=hip.ptr(stats),
-                           N=n, S=s, C=c, act=act, eps=eps)
+                           N=n, S=s, C=c, act=act, eps=eps, act_beta=_scalar_ptr(act, act_beta))
     _launch("sample_norm_fwd_kernel", lambda: (_nb(a, b, y, gamma, beta, stats), 0.0, f"S{s} C{c} a{act}"),
             lambda: hip.call("ddpm_sample_norm_forward", C.byref(d), hip.stream()))
     return y, stats
 
 
-def sample_norm_backward(a: Tensor, b: Optional[Tensor], dy: Tensor, act: int, gamma: Tensor, stats: Tensor, part: Tensor, eps: float = 1e-5):
+def sample_norm_backward(a: Tensor, b: Optional[Tensor], dy: Tensor, act: int, gamma: Tensor, stats: Tensor, part: Tensor, eps: float = 1e-5,
+                         act_beta: Optional[Tensor] = None, dbeta_part: Optional[Tensor] = None):
     """Returns (du, da): gradients w.r.t. (act(a) + b) and w.r.t. a (the same tensor when act is the identity).
     part: fp32 [N][3][C] receives d gamma, d beta and the column sums of da per sample."""
     n, s, c = a.shape[0], a.numel() // (a.shape[0] * a.shape[-1]), a.shape[-1]
@@ -417,7 +432,9 @@ def sample_norm_backward(a: Tensor, b: Optional[Tensor], dy: Tensor, act: int, g
     du = torch.empty_like(a)
     da = torch.empty_like(a) if act else None
     d = hip.SampleNormDesc(a=hip.ptr(a), b=hip.ptr(b), gamma=hip.ptr(gamma), beta=None, y=None, stats=hip.ptr(stats), dy=hip.ptr(dy),
-                           du=hip.ptr(du), da=hip.ptr(da), part=hip.ptr(part), N=n, S=s, C=c, act=act, eps=eps)
+                           du=hip.ptr(du), da=hip.ptr(da), part=hip.ptr(part), N=n, S=s, C=c, act=act, eps=eps,
+                           act_beta=_scalar_ptr(act, act_beta), dbeta_part=hip.ptr(dbeta_part))
+    assert act not in hip.ACT_WITH_SCALAR or (dbeta_part is not None and dbeta_part.numel() == n)
     _launch("sample_norm_bwd_kernel", lambda: (_nb(a, b, dy, du, da, gamma, stats, part), 0.0, f"S{s} C{c} a{act}"),
             lambda: hip.call("ddpm_sample_norm_backward", C.byref(d), hip.stream()))
     return du, (da if act else du)
@@ -452,13 +469,14 @@ def reduce_rows(src: Tensor, dst: Tensor, entries: Tensor, n_entries: int, max_w
 
 
 def reduce_table(entries, device) -> Tensor:
-    """Device copy of a list of (src_off, dst_off, rows, row_stride, width) tuples."""
+    """Device copy of a list of (src_off, dst_off, rows, row_stride, width) tuples.  row_stride 0 marks a scalar fold: the
+    `rows` contiguous floats at src_off are summed into the single number at dst_off."""
     import numpy as np
     arr = np.zeros((len(entries), 4), dtype=np.int64)
     for i, (so, do, rows, stride, width) in enumerate(entries):
         arr[i, 0], arr[i, 1] = so, do
         arr[i, 2] = (rows & 0xFFFFFFFF) | (stride << 32)
-        arr[i, 3] = width
+        arr[i, 3] = width | ((1 << 32) if stride == 0 else 0)
     return torch.from_numpy(arr).to(device)
 
 

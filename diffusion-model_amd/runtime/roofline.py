@@ -75,10 +75,11 @@ def measure(step: Callable[[], None], reps: int = 3, traffic_file: str = "", det
     top = max(table, key=lambda k: table[k]["ms_per_step"])
     t = table[top]
     hbm_frac, mfma_frac = t["GB/s"] / HBM_PEAK_GBS, t["TFLOP/s"] / MFMA_BF16_PEAK_TFLOPS
-    traffic = None
+    traffic, measured = None, {}
     if traffic_file and os.path.exists(traffic_file):      # HBM bytes per launch from a separate counter pass, when recorded
         with open(traffic_file) as f:
-            traffic = json.load(f).get(top, {}).get("hbm_bytes_per_launch")
+            measured = json.load(f)
+        traffic = measured.get(top, {}).get("hbm_bytes_per_launch")
     if hbm_frac >= mfma_frac:
         out = {"bound": "hbm", "achieved": t["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
     else:
@@ -91,5 +92,11 @@ def measure(step: Callable[[], None], reps: int = 3, traffic_file: str = "", det
                    "hbm_frac": tot_b / tot_sec * 1e-9 / HBM_PEAK_GBS, "mfma_frac": tot_f / tot_sec * 1e-12 / MFMA_BF16_PEAK_TFLOPS}
     out.update({"traffic": traffic, "kernel": top, "launches_per_step": t["launches_per_step"], "avg_us": t["avg_us"],
                 "algorithmic_bytes_per_launch": t["bytes_per_launch"],
-                "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items() if kk != "bytes_per_launch"} for k, v in table.items()}})
+                # per kernel family, over the same eager launches: algorithmic bytes per launch beside the HBM bytes per launch
+                # the counter pass measured (below the algorithmic figure where operands are still in the last-level cache
+                # from their producer, above it where a kernel re-reads)
+                "kernels": {k: dict({kk: round(vv, 3) for kk, vv in v.items() if kk != "bytes_per_launch"},
+                                    algorithmic_bytes_per_launch=round(v["bytes_per_launch"]),
+                                    hbm_bytes_per_launch=(round(measured[k]["hbm_bytes_per_launch"]) if k in measured else None))
+                            for k, v in table.items()}})
     return out

@@ -184,6 +184,11 @@ typedef struct ddpm_gn_desc {
                                * for one workgroup per (image, channel slab) are processed by many workgroups in two launches
                                * (partial sums, then apply); without it one workgroup walks the slab */
     int64_t scratch_floats;
+    const float* act_beta;    /* act = swish / hardswish: device pointer to the activation's learnable scalar b
+                               * (neural_nets/activations.py:40,60: z * sigmoid(b z), z * hardsigmoid(b z)); else unused */
+    float* dbeta_part;        /* backward, swish / hardswish: fp32 [N][C], written once: per image and channel sums of
+                               * dy * mask * d act / d b.  The scalar's gradient is the sum of all N*C entries
+                               * (ddpm_reduce_rows entry with scalar = 1). */
 } ddpm_gn_desc;
 
 /* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:
@@ -216,7 +221,9 @@ int ddpm_dwconv3x3_wgrad_blocks(int N, int H, int W, int C);
 
 /* dst[e.dst_off + j] += sum_{r < e.rows} src[e.src_off + r * e.row_stride + j], j < e.width, for every entry: the second
  * stage of the partial-sum reductions above, all layers in one launch.  entries: device array. */
-typedef struct ddpm_reduce_entry { int64_t src_off; int64_t dst_off; int32_t rows; int32_t row_stride; int32_t width; int32_t pad; } ddpm_reduce_entry;
+/* scalar = 1: dst[e.dst_off] += sum_{i < e.rows} src[e.src_off + i] (a contiguous run folded to one number by a whole
+ * workgroup; row_stride and width are ignored): the gradient of an activation's learnable scalar. */
+typedef struct ddpm_reduce_entry { int64_t src_off; int64_t dst_off; int32_t rows; int32_t row_stride; int32_t width; int32_t scalar; } ddpm_reduce_entry;
 int ddpm_reduce_rows(const float* src, float* dst, const ddpm_reduce_entry* entries, int n_entries, int max_width,
                      ddpm_stream_t stream);
 
@@ -406,6 +413,8 @@ typedef struct ddpm_sample_norm_desc {
     float* part;
     int32_t N, S, C, act;
     float eps;
+    const float* act_beta;   /* act = swish / hardswish: the activation's learnable scalar (device pointer) */
+    float* dbeta_part;       /* backward, swish / hardswish: fp32 [N], per-sample partial sums of the scalar's gradient */
 } ddpm_sample_norm_desc;
 int ddpm_sample_norm_forward(const ddpm_sample_norm_desc* d, ddpm_stream_t stream);
 int ddpm_sample_norm_backward(const ddpm_sample_norm_desc* d, ddpm_stream_t stream);

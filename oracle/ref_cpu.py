@@ -71,8 +71,22 @@ class UNetCfg:
         return 8 * self.base_groups_norm
 
 
-def act_fn(name: str):
-    """Parameter-free activations of the reference registry (neural_nets/activations.py:102-114)."""
+BETA_ACTS = ("swish", "hardswish")
+
+
+def act_fn(name: str, p: Optional[Params] = None):
+    """Activations of the reference registry (neural_nets/activations.py:102-114) as act(x, site): `site` is the state_dict
+    prefix of the activation module at that place of the network.  The parameter-free ones ignore it; swish and hardswish
+    (activations.py:25-63: x * sigmoid(beta x), x * hardsigmoid(beta x)) read their learnable scalar p[site + ".beta"]."""
+    if name in BETA_ACTS:
+        gate = torch.sigmoid if name == "swish" else F.hardsigmoid
+        assert p is not None, f"{name} needs the parameter dictionary"
+        return lambda x, site: x * gate(p[site + ".beta"] * x)
+    f = _PLAIN_ACTS()[name]
+    return lambda x, site=None: f(x)
+
+
+def _PLAIN_ACTS():
     table = {
         "gelu": lambda x: F.gelu(x, approximate="none"),
         "silu": F.silu,
@@ -84,7 +98,7 @@ def act_fn(name: str):
         "leaky_relu": lambda x: F.leaky_relu(x, 0.05),
         "selu": F.selu,
     }
-    return table[name]
+    return table
 
 
 # --------------------------------------------------------------------------- schedule
@@ -155,7 +169,7 @@ def sinusoidal(t_norm: Tensor, dim: int) -> Tensor:
 def embed_block(p: Params, pre: str, temb: Tensor, act) -> Tensor:
     """EmbedBlock: Linear -> act -> Linear -> (N,C,1,1)   (constituent_blocks.py:308-328)."""
     h = _r(F.linear(_r(temb), _r(p[pre + "layers.0.weight"]), p[pre + "layers.0.bias"]))
-    h = F.linear(_r(act(h)), _r(p[pre + "layers.2.weight"]), p[pre + "layers.2.bias"])
+    h = F.linear(_r(act(h, pre + "layers.1")), _r(p[pre + "layers.2.weight"]), p[pre + "layers.2.bias"])
     return h[:, :, None, None]
 
 
@@ -183,17 +197,17 @@ def conv_gn_act(p: Params, conv: str, gn: str, x: Tensor, groups: int, act, *, s
     else:
         y = F.conv2d(x, _r(p[conv + "weight"]), p[conv + "bias"], stride=stride, padding=1)
     y = F.group_norm(_r(y), groups, p[gn + "weight"], p[gn + "bias"], eps=1e-5)
-    return _r(act(y))
+    return _r(act(y, gn[:-2] + "2"))          # Sequential(conv, GroupNorm, activation): the activation is module 2
 
 
 def sir_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
     """SeparableInvertResidual.forward (conv_block.py:57-136): three conv+GN stages, each fed a
     dropped-out input; the residual adds the un-dropped block input."""
     e = _r(F.conv2d(_r(drop(x)), _r(p[pre + "expansion.1.weight"]), p[pre + "expansion.1.bias"]))
-    e = _r(drop(act(F.group_norm(e, groups, p[pre + "expansion.2.weight"], p[pre + "expansion.2.bias"], eps=1e-5))))
+    e = _r(drop(act(F.group_norm(e, groups, p[pre + "expansion.2.weight"], p[pre + "expansion.2.bias"], eps=1e-5), pre + "expansion.3")))
     c = e.shape[1]
     d = _r(F.conv2d(e, p[pre + "depthwise.1.weight"], p[pre + "depthwise.1.bias"], padding=1, groups=c))
-    d = _r(drop(act(F.group_norm(d, groups, p[pre + "depthwise.2.weight"], p[pre + "depthwise.2.bias"], eps=1e-5))))
+    d = _r(drop(act(F.group_norm(d, groups, p[pre + "depthwise.2.weight"], p[pre + "depthwise.2.bias"], eps=1e-5), pre + "depthwise.3")))
     o = _r(F.conv2d(d, _r(p[pre + "projection.1.weight"]), p[pre + "projection.1.bias"]))
     o = F.group_norm(o, groups, p[pre + "projection.2.weight"], p[pre + "projection.2.bias"], eps=1e-5)
     if o.shape == x.shape:
@@ -243,7 +257,7 @@ def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: st
 
     taps, when given, is filled with named intermediate tensors (stage outputs, latent,
     pre-Tanh logits) so per-layer parity can be checked."""
-    act = act_fn(cfg.activation)
+    act = act_fn(cfg.activation, p)
     drop = drop or DropMasks()
     g = cfg.groups
     nst = len(cfg.stages_channels)
@@ -256,7 +270,7 @@ def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: st
 
     # ---- encoder (unets.py:121-132)
     temb = sinusoidal(time.float() / cfg.time_norm, cfg.t_embed_dim)
-    z = _r(act(_r(F.conv2d(_r(x), _r(p[enc + "stem_layers.0.weight"]), p[enc + "stem_layers.0.bias"], padding=1))))
+    z = _r(act(_r(F.conv2d(_r(x), _r(p[enc + "stem_layers.0.weight"]), p[enc + "stem_layers.0.bias"], padding=1)), enc + "stem_layers.1"))
     tap("enc.stem", z)
     skips = []
     for i in range(nst):
@@ -264,7 +278,8 @@ def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: st
                        cfg.attention_depth if i in cfg.attention_stages else 0)
         skips.append(tap(f"enc.stage{i}", z))
     z = _r(F.conv2d(z, _r(p[enc + "latent_layers.0.weight"]), p[enc + "latent_layers.0.bias"], padding=1))
-    z = _r(act(F.group_norm(z, cfg.latent_groups, p[enc + "latent_layers.1.weight"], p[enc + "latent_layers.1.bias"], eps=1e-5)))
+    z = _r(act(F.group_norm(z, cfg.latent_groups, p[enc + "latent_layers.1.weight"], p[enc + "latent_layers.1.bias"], eps=1e-5),
+               enc + "latent_layers.2"))
     tap("enc.latent", z)
 
     # ---- decoder (unets.py:230-240)
@@ -275,7 +290,7 @@ def unet_forward(p: Params, cfg: UNetCfg, x: Tensor, time: Tensor, *, prefix: st
         z = up_block(p, f"{dec}layers.{i}.", _r(z + embed_block(p, f"{dec}t_embeddings.{i}.", temb, act)), skips[i], g, act, drop,
                      cfg.attention_depth if nst - 1 - i in cfg.attention_stages else 0)
         tap(f"dec.stage{i}", z)
-    z = _r(act(_r(F.conv2d(z, _r(p[dec + "out_layers.0.weight"]), p[dec + "out_layers.0.bias"], padding=1))))
+    z = _r(act(_r(F.conv2d(z, _r(p[dec + "out_layers.0.weight"]), p[dec + "out_layers.0.bias"], padding=1)), dec + "out_layers.1"))
     z = F.conv2d(z, _r(p[dec + "out_layers.2.weight"]), p[dec + "out_layers.2.bias"], padding=1)
     tap("dec.logits", z)
     return torch.tanh(z)
@@ -331,13 +346,13 @@ def conditional_module(p: Params, pre: str, query: Tensor, cond: Tensor, depth: 
         r = _r(o + z).transpose(1, 2).unsqueeze(-1)
         r = _r(F.group_norm(r, 1, p[f"{pre}mha_norms.{i}.weight"], p[f"{pre}mha_norms.{i}.bias"], eps=1e-5))
         h = _r(F.linear(r.squeeze(-1).transpose(1, 2), _r(p[f"{pre}linears.{i}.weight"]), p[f"{pre}linears.{i}.bias"]))
-        h = act(h).transpose(1, 2).unsqueeze(-1) + r
+        h = act(h, f"{pre}activations.{i}").transpose(1, 2).unsqueeze(-1) + r
         h = _r(F.group_norm(h, 1, p[f"{pre}linear_norms.{i}.weight"], p[f"{pre}linear_norms.{i}.bias"], eps=1e-5))
         z = h.squeeze(-1).transpose(1, 2)
     return z
 
 
-def conditional_shapes(pre: str, c: int, depth: int, kdim: Optional[int] = None) -> Dict[str, Tuple[int, ...]]:
+def conditional_shapes(pre: str, c: int, depth: int, kdim: Optional[int] = None, beta: bool = False) -> Dict[str, Tuple[int, ...]]:
     """state_dict keys and shapes of ConditionalModule(c, act, depth, p, kdim, kdim) in registration order
     (constituent_blocks.py:357-399; nn.MultiheadAttention registers in_proj_weight - or q/k/v_proj_weight when
     kdim != embed_dim - then in_proj_bias, then out_proj)."""
@@ -357,14 +372,19 @@ def conditional_shapes(pre: str, c: int, depth: int, kdim: Optional[int] = None)
             else:
                 out[f"{pre}{name}.{i}.weight"] = (c,)
             out[f"{pre}{name}.{i}.bias"] = (c,)
+    if beta:                                             # self.activations, registered last (constituent_blocks.py:398-399)
+        for i in range(depth):
+            out[f"{pre}activations.{i}.beta"] = ()
     return out
 
 
-def hash_conditional_params(pre: str, c: int, depth: int, kdim: Optional[int] = None, seed_base: int = 700) -> Params:
+def hash_conditional_params(pre: str, c: int, depth: int, kdim: Optional[int] = None, seed_base: int = 700, beta: bool = False) -> Params:
     """Deterministic ConditionalModule parameters (the rule tools/gen_golden.py used for conditional_module.pt)."""
     p: Params = {}
-    for i, (k, shp) in enumerate(conditional_shapes(pre, c, depth, kdim).items()):
-        if len(shp) >= 2:
+    for i, (k, shp) in enumerate(conditional_shapes(pre, c, depth, kdim, beta).items()):
+        if k.endswith(".beta"):
+            p[k] = hash_fill((1,), seed_base + i, 0.3, 1.0).reshape(())
+        elif len(shp) >= 2:
             p[k] = hash_fill(shp, seed_base + i, (3.0 / shp[-1]) ** 0.5)
         elif "norm" in k and k.endswith("weight"):
             p[k] = hash_fill(shp, seed_base + i, 0.2, 1.0)
@@ -429,6 +449,7 @@ def param_shapes(cfg: UNetCfg, prefix: str = "model.") -> Dict[str, Tuple[int, .
     out: Dict[str, Tuple[int, ...]] = {}
     st = list(cfg.stages_channels)
     te = cfg.t_embed_dim
+    has_beta = cfg.activation in BETA_ACTS
 
     def conv(name, co, ci, k):
         out[name + "weight"] = (co, ci, k, k)
@@ -438,49 +459,55 @@ def param_shapes(cfg: UNetCfg, prefix: str = "model.") -> Dict[str, Tuple[int, .
         out[name + "weight"] = (c,)
         out[name + "bias"] = (c,)
 
+    def actp(site):
+        """the activation module at `site`: swish / hardswish register one 0-dim parameter (activations.py:40,60)"""
+        if has_beta:
+            out[site + ".beta"] = ()
+
     def sir(name, c):
         e = int(cfg.expand_factor * c)
-        conv(name + "expansion.1.", e, c, 1); norm(name + "expansion.2.", e)
-        conv(name + "depthwise.1.", e, 1, 3); norm(name + "depthwise.2.", e)
+        conv(name + "expansion.1.", e, c, 1); norm(name + "expansion.2.", e); actp(name + "expansion.3")
+        conv(name + "depthwise.1.", e, 1, 3); norm(name + "depthwise.2.", e); actp(name + "depthwise.3")
         conv(name + "projection.1.", c, e, 1); norm(name + "projection.2.", c)
 
     def embed(name, c):
         out[name + "layers.0.weight"] = (2 * c, te); out[name + "layers.0.bias"] = (2 * c,)
+        actp(name + "layers.1")
         out[name + "layers.2.weight"] = (c, 2 * c); out[name + "layers.2.bias"] = (c,)
 
     e = prefix + "encoder."
-    conv(e + "stem_layers.0.", st[0], cfg.img_channels, 3)
+    conv(e + "stem_layers.0.", st[0], cfg.img_channels, 3); actp(e + "stem_layers.1")
     ins = [st[0]] + st[:-1]
     for i, (ci, co) in enumerate(zip(ins, st)):
         b = f"{e}layers.{i}.layers."
-        conv(b + "0.0.", co, ci, 3); norm(b + "0.1.", co)
+        conv(b + "0.0.", co, ci, 3); norm(b + "0.1.", co); actp(b + "0.2")
         k = 1
         if i in cfg.attention_stages:
-            out.update(conditional_shapes(b + "1.", co, cfg.attention_depth))
+            out.update(conditional_shapes(b + "1.", co, cfg.attention_depth, beta=has_beta))
             k = 2
         sir(f"{b}{k}.", co); sir(f"{b}{k + 1}.", co)
-        conv(f"{b}{k + 2}.0.", co, co, 3); norm(f"{b}{k + 2}.1.", co)
+        conv(f"{b}{k + 2}.0.", co, co, 3); norm(f"{b}{k + 2}.1.", co); actp(f"{b}{k + 2}.2")
     for i, ci in enumerate(ins):
         embed(f"{e}t_embeddings.{i}.", ci)
-    conv(e + "latent_layers.0.", cfg.latent_dim, st[-1], 3); norm(e + "latent_layers.1.", cfg.latent_dim)
+    conv(e + "latent_layers.0.", cfg.latent_dim, st[-1], 3); norm(e + "latent_layers.1.", cfg.latent_dim); actp(e + "latent_layers.2")
 
     d = prefix + "decoder."
     rs = st[::-1]
-    conv(d + "decoder_input_layers.0.", rs[0], cfg.latent_dim, 3); norm(d + "decoder_input_layers.1.", rs[0])
+    conv(d + "decoder_input_layers.0.", rs[0], cfg.latent_dim, 3); norm(d + "decoder_input_layers.1.", rs[0]); actp(d + "decoder_input_layers.2")
     outs = rs[1:] + [rs[-1]]
     for i, (ci, co) in enumerate(zip(rs, outs)):
         b = f"{d}layers.{i}.layers."
-        conv(b + "0.0.", ci, 2 * ci, 3); norm(b + "0.1.", ci)
+        conv(b + "0.0.", ci, 2 * ci, 3); norm(b + "0.1.", ci); actp(b + "0.2")
         k = 1
         if len(st) - 1 - i in cfg.attention_stages:
-            out.update(conditional_shapes(b + "1.", ci, cfg.attention_depth))
+            out.update(conditional_shapes(b + "1.", ci, cfg.attention_depth, beta=has_beta))
             k = 2
         sir(f"{b}{k}.", ci)
-        out[f"{b}{k + 1}.0.weight"] = (ci, co, 2, 2); out[f"{b}{k + 1}.0.bias"] = (co,); norm(f"{b}{k + 1}.1.", co)
+        out[f"{b}{k + 1}.0.weight"] = (ci, co, 2, 2); out[f"{b}{k + 1}.0.bias"] = (co,); norm(f"{b}{k + 1}.1.", co); actp(f"{b}{k + 1}.2")
         sir(f"{b}{k + 2}.", co); sir(f"{b}{k + 3}.", co)
     for i, ci in enumerate(rs):
         embed(f"{d}t_embeddings.{i}.", ci)
-    conv(d + "out_layers.0.", rs[-1], rs[-1], 3)
+    conv(d + "out_layers.0.", rs[-1], rs[-1], 3); actp(d + "out_layers.1")
     conv(d + "out_layers.2.", cfg.img_channels, rs[-1], 3)
     return out
 
@@ -504,6 +531,8 @@ def hash_params(cfg: UNetCfg, seed: int = 1, prefix: str = "model.", residual_ga
             p[k] = hash_fill(shp, seed * 1000 + i, math.sqrt(3.0 / fan_in))
         elif k.endswith("weight"):
             p[k] = hash_fill(shp, seed * 1000 + i, 0.3, 1.0)
+        elif k.endswith(".beta"):                                              # an activation's scalar: 1 +- 0.3
+            p[k] = hash_fill((1,), seed * 1000 + i, 0.3, 1.0).reshape(())
         else:
             norm_bias = any(t in k for t in (".0.1.bias", ".3.1.bias", ".2.1.bias", "expansion.2.bias", "depthwise.2.bias",
                                               "projection.2.bias", "latent_layers.1.bias", "decoder_input_layers.1.bias"))

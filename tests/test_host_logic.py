@@ -53,13 +53,37 @@ def test_no_cpu_fallback():
         SeparableInvertResidual(32, 32, expand_factor=2, activation="gelu")(torch.zeros(1, 32, 8, 8))
 
 
-def test_learnable_activations_are_rejected_loudly():
-    from dm_amd.neural_nets.activations import activation_code
-    for name in ("swish", "hardswish"):
-        with pytest.raises(NotImplementedError):
-            activation_code(name)
-    for name in ("gelu", "silu", "relu", "relu6", "leaky_relu", "selu", "hardsigmoid", "sigmoid", "tanh"):
+def test_learnable_activations_register_the_reference_keys(golden):
+    """swish / hardswish own one 0-dim `beta` per activation module (neural_nets/activations.py:25-63 of the reference): the
+    modules here register them under the reference's state_dict keys, in its registration order, initialised to 1.  The
+    expected key lists are those of the reference modules the fixture was generated from (tools/gen_golden.py), and
+    oracle.ref_cpu.param_shapes, which that generator checked against the reference DDPM's state_dict."""
+    from dm_amd.neural_nets.activations import activation_code, has_scalar
+    from dm_amd.neural_nets.denoise_models.constituent_blocks import ConditionalModule
+    from oracle import ref_cpu as O
+    for name in ("gelu", "silu", "relu", "relu6", "leaky_relu", "selu", "hardsigmoid", "sigmoid", "tanh", "swish", "hardswish"):
         assert activation_code(name) > 0
+        assert has_scalar(name) == (name in ("swish", "hardswish"))
+    g = golden("beta_activations.pt")
+    for act in ("swish", "hardswish"):
+        kw = dict(expand_factor=2, drop_p=0.0, base_groups_norm=4, initializer="he_normal", activation=act)
+        sir = SeparableInvertResidual(32, 32, **kw)
+        assert list(sir.state_dict()) == list(g[f"sir.{act}"]["params"])
+        assert sir.state_dict()["expansion.3.beta"].shape == () and float(sir.state_dict()["depthwise.3.beta"]) == 1.0
+        assert list(EmbedBlock(32, 64, act, "he_normal").state_dict()) == list(g[f"embed.{act}"]["params"])
+        assert list(ConditionalModule(32, act, 1, 0.0, 32, 32).state_dict()) == list(g[f"conditional.{act}"]["dparams"])
+        cfg = O.UNetCfg(img_channels=1, stages_channels=(32, 64), latent_dim=64, activation=act)
+        m = dm_ddpm.DDPM(dm_unets.BaseUNet, **dict(YAML, activation=act, stages_channels=[32, 64]), is_conditional=False, img_channels=1,
+                         reconstruction_method="mse", latent_dim=64, device="cpu")
+        want = O.param_shapes(cfg)
+        assert list(m.state_dict()) == list(want)
+        assert all(tuple(v.shape) == want[k] for k, v in m.state_dict().items())
+        assert len(g[f"unet.{act}"]["beta_grads"]) == sum(k.endswith(".beta") for k in want) == 36
+        down = DownBlock(in_channels=32, out_channels=64, is_conditional=False, **kw)
+        assert [k for k in down.state_dict() if k.endswith("beta")] == ["layers.0.2.beta", "layers.1.expansion.3.beta", "layers.1.depthwise.3.beta",
+                                                                        "layers.2.expansion.3.beta", "layers.2.depthwise.3.beta", "layers.3.2.beta"]
+        up = UpBlock(in_channels=64, out_channels=32, is_conditional=False, **kw)
+        assert [k for k in up.state_dict() if k.endswith("beta") and "layers.0." in k or k == "layers.2.2.beta"] == ["layers.0.2.beta", "layers.2.2.beta"]
 
 
 def test_reference_error_conventions():

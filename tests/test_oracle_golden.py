@@ -186,3 +186,54 @@ def test_philox_oracle_known_answers():
         assert got == want
     t = sample_timesteps(10000, 120, 42, 3)
     assert t.min() == 1 and t.max() == 120 and t.dtype == np.int64
+
+
+@pytest.mark.parametrize("act", ["swish", "hardswish"])
+def test_learnable_scalar_activations(golden, act):
+    """swish / hardswish (neural_nets/activations.py:25-63 of the reference): one learnable scalar per activation module.
+    The oracle against the reference's inverted-residual block, EmbedBlock, ConditionalModule and a small whole network,
+    forward and gradients, the scalars' gradients included."""
+    g = golden("beta_activations.pt")
+    rec = g[f"sir.{act}"]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in rec["params"].items()}
+    x = rec["x"].clone().requires_grad_(True)
+    y = O.sir_block(leaves, "", x, 16, O.act_fn(act, leaves), O.DropMasks())
+    close(y, rec["y"], 1e-4, 1e-5)
+    grads = torch.autograd.grad(y, [x] + list(leaves.values()), rec["gy"])
+    close(grads[0], rec["gx"], 1e-4, 1e-4)
+    for k, gp in zip(leaves, grads[1:]):
+        close(gp, rec["gparams"][k], 1e-4, 2e-4)
+    assert rec["gparams"]["expansion.3.beta"].shape == () and abs(float(rec["gparams"]["expansion.3.beta"])) > 1.0
+
+    e = g[f"embed.{act}"]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in e["params"].items()}
+    ye = O.embed_block(leaves, "", e["sin"], O.act_fn(act, leaves))
+    close(ye, e["y"])
+    for k, gp in zip(leaves, torch.autograd.grad(ye, list(leaves.values()), e["gy"])):
+        close(gp, e["gparams"][k], 1e-4, 1e-5)
+
+    c = g[f"conditional.{act}"]
+    p = {k: v.requires_grad_(True) for k, v in O.hash_conditional_params("", c["C"], 1, c["C"], seed_base=c["param_seed_base"], beta=True).items()}
+    q = hash_normal((2, c["S"], c["C"]), c["q_seed"]).requires_grad_(True)
+    yc = O.conditional_module(p, "", q, q, 1, O.act_fn(act, p))
+    close(yc, c["y"], 1e-4, 1e-5)
+    gc = torch.autograd.grad(yc, [q] + list(p.values()), hash_normal(tuple(yc.shape), c["gy_seed"]))
+    close(gc[0], c["dq"], 1e-3, 1e-4)
+    for k, gp in zip(p, gc[1:]):
+        close(gp, c["dparams"][k], 1e-3, 2e-4)
+
+    u = g[f"unet.{act}"]
+    cfg = O.UNetCfg(img_channels=1, stages_channels=(32, 64), latent_dim=64, activation=act, drop_p=0.0)
+    pu = O.hash_params(cfg, seed=1)
+    assert sum(v.numel() for v in pu.values()) == u["n_params"]
+    s = O.make_schedule(120, 0.25)
+    noise = hash_normal(tuple(u["x0"].shape), 401)
+    assert torch.equal(O.q_sample(s, u["x0"], u["t"], noise), u["x_t"])
+    with torch.no_grad():
+        close(O.unet_forward(pu, cfg, u["x_t"], u["t"]), u["pred"], 2e-4, 2e-5)
+    loss, grads = O.train_step_grads(pu, cfg, s, u["x0"], u["t"], noise)
+    close(loss, u["loss"], 1e-4, 1e-7)
+    for k, d in u["grad_digest"].items():
+        _digest_close(grads[k], d, 2e-3)
+    for k, v in u["beta_grads"].items():
+        close(grads[k], v, 2e-3, 1e-6)

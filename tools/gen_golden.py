@@ -323,8 +323,62 @@ def gen_conditional():
     save("conditional_module.pt", out)
 
 
+def gen_beta_activations():
+    """swish / hardswish (one learnable scalar per activation module, activations.py:25-63): an inverted-residual block, an
+    EmbedBlock, a self-attention ConditionalModule and a small whole network, forward and all gradients."""
+    out = {}
+    for act in ("swish", "hardswish"):
+        kw = dict(expand_factor=2, drop_p=0.0, base_groups_norm=4, activation=act, initializer="he_normal")
+        blk = SeparableInvertResidual(32, 32, **kw).eval()
+        sd = {k: (O.hash_fill((1,), 7 + i, 0.3, 1.0).reshape(()) if k.endswith("beta") else
+                  O.hash_fill(v.shape, 7 + i, 0.25, 1.0 if (k.endswith("2.weight")) else 0.0)) for i, (k, v) in enumerate(blk.state_dict().items())}
+        blk.load_state_dict(sd)
+        x = hash_normal((2, 32, 8, 8), 31).requires_grad_(True)
+        y = blk(x)
+        gy = hash_normal(tuple(y.shape), 32)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        out[f"sir.{act}"] = {"params": sd, "x": x.detach(), "y": y.detach(), "gy": gy, "gx": grads[0],
+                             "gparams": dict(zip(sd.keys(), grads[1:]))}
+        emb = ref_blocks.EmbedBlock(32, 64, act, "he_normal")
+        sd = {k: (O.hash_fill((1,), 257 + i, 0.3, 1.0).reshape(()) if k.endswith("beta") else O.hash_fill(v.shape, 257 + i, 0.2))
+              for i, (k, v) in enumerate(emb.state_dict().items())}
+        emb.load_state_dict(sd)
+        t = torch.tensor([1, 50, 120])
+        sin = ref_blocks.SinusoidalPositionEmbedBlock(32)(t.float() / 100)
+        ye = emb(sin)
+        gye = hash_normal(tuple(ye.shape), 33)
+        ge = torch.autograd.grad(ye, list(emb.parameters()), gye)
+        out[f"embed.{act}"] = {"params": sd, "t": t, "sin": sin, "y": ye.detach(), "gy": gye, "gparams": dict(zip(sd.keys(), ge))}
+        # self-attention ConditionalModule, C = 32, 64 tokens
+        mod = ref_blocks.ConditionalModule(32, act, 1, 0.0, 32, 32).eval()
+        params = O.hash_conditional_params("", 32, 1, 32, seed_base=900, beta=True)
+        assert list(mod.state_dict()) == list(params), (list(mod.state_dict()), list(params))
+        mod.load_state_dict(params)
+        qq = hash_normal((2, 64, 32), 811).requires_grad_(True)
+        yc = mod(qq, qq)
+        gyc = hash_normal(tuple(yc.shape), 813)
+        gc = torch.autograd.grad(yc, [qq] + list(mod.parameters()), gyc)
+        out[f"conditional.{act}"] = {"C": 32, "S": 64, "param_seed_base": 900, "q_seed": 811, "gy_seed": 813, "y": yc.detach(), "dq": gc[0],
+                                     "dparams": {k: g for (k, _), g in zip(mod.named_parameters(), gc[1:])}}
+        # whole network: stages [32, 64], latent 64, 1 channel, 16x16
+        m, cfg, params = build_ddpm(img_channels=1, activation=act, stages=(32, 64), latent=64)
+        m.eval()
+        x0 = hash_uniform((2, 1, 16, 16), 301) * 2 - 1
+        t = torch.tensor([7, 93])
+        with patched_noise(400):
+            x_t = m.q(x0, t)
+        pred = m(x_t, t)
+        loss = ELBOLoss("mse")(m, t, pred, x0)["Loss"]
+        loss.backward()
+        out[f"unet.{act}"] = {"x0": x0, "t": t, "x_t": x_t, "pred": pred.detach(), "loss": loss.detach(),
+                              "grad_digest": {k: grad_digest(v.grad) for k, v in m.named_parameters()},
+                              "beta_grads": {k: v.grad.clone() for k, v in m.named_parameters() if k.endswith(".beta")},
+                              "n_params": sum(p.numel() for p in m.parameters())}
+    save("beta_activations.pt", out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_schedule_and_ops, gen_blocks, gen_unet_full, gen_sample_chain, gen_conditional):
+    for fn in (gen_schedule_and_ops, gen_blocks, gen_unet_full, gen_sample_chain, gen_conditional, gen_beta_activations):
         if not only or fn.__name__ in only:
             fn()

@@ -35,13 +35,25 @@ def family(name: str) -> str:
     return re.split(r"[<(]", name)[0].strip()
 
 
-def counter(dirname: str, which: str):
+def instance(name: str) -> str:
+    """template instance without the argument list: conv_img_kernel<8, 1, 1, 1, 512, 0>"""
+    name = re.sub(r"^void ", "", name)
+    depth = 0
+    for i, ch in enumerate(name):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i].strip()
+    return name.strip()
+
+
+def counter(dirname: str, which: str, key=family):
     f = glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True)[0]
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != which:
             continue
-        a = acc[family(r["Kernel_Name"])]
+        a = acc[key(r["Kernel_Name"])]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
     return acc
@@ -62,16 +74,24 @@ def main():
         json.dump(out, open(sys.argv[4], "w"), indent=1)
     elif sys.argv[1] == "mfma":
         names = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE")
-        cs = {n: counter(sys.argv[2], n) for n in names}
+        out = {}
+        for key, into in ((family, out), (instance, out.setdefault("by_template_instance", {}))):
+            mfma_rows(names, key, into)
+        json.dump(out, open(sys.argv[4], "w"), indent=1)
+    else:
+        raise SystemExit(__doc__)
+
+
+def mfma_rows(names, key, out):
+        cs = {n: counter(sys.argv[2], n, key) for n in names}
         dur = {}
         f = glob.glob(os.path.join(sys.argv[3], "**", "*_kernel_stats.csv"), recursive=True)
         if f:
             tot = collections.defaultdict(lambda: [0, 0.0])
             for r in csv.DictReader(open(f[0])):
-                t = tot[family(r["Name"])]
+                t = tot[key(r["Name"])]
                 t[0] += int(r["Calls"]); t[1] += float(r["TotalDurationNs"])
             dur = {k: v[1] / max(1, v[0]) for k, v in tot.items()}
-        out = {}
         for k in sorted(cs[names[0]]):
             n = cs[names[0]][k][0]
             busy, cu, mops, gui = (cs[q].get(k, [1, 0.0])[1] / max(1, cs[q].get(k, [1, 0.0])[0]) for q in names)
@@ -86,9 +106,6 @@ def main():
                 row["bf16_tflops"] = mops * 512 / dur[k] * 1e-3
                 row["frac_of_2500_tflops"] = row["bf16_tflops"] / 2500.0
             out[k] = row
-        json.dump(out, open(sys.argv[4], "w"), indent=1)
-    else:
-        raise SystemExit(__doc__)
 
 
 if __name__ == "__main__":

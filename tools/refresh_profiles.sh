@@ -17,4 +17,11 @@ python3 $R/tools/profile_summary.py traffic /tmp/prof/fetch /tmp/prof/write $OUT
 # matrix-core evidence: one counter pass of its own (no trace domains beside --pmc), the program directly after --
 timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof/mfma -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-sample --no-cpu --no-roofline --no-graph --no-extra > /tmp/prof/mfma.out 2> /tmp/prof/mfma.err
 python3 $R/tools/profile_summary.py mfma /tmp/prof/mfma /tmp/prof/stats $OUT/mfma_util.json
+# the same two passes on the 64x64x3 training step (batch 128): the 3x3 convolutions with Cin >= 128 at 32x32 and 16x16 positions
+# are the matrix-core-bound shapes of this network
+B64="--size 64 --channels 3 --batch 128 --no-sample --no-cpu --no-roofline --no-extra"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats64 -o r -- python3 $R/bench.py --steps 10 --warmup 3 $B64 > /tmp/prof/stats64.out 2> /tmp/prof/stats64.err
+python3 $R/tools/profile_summary.py stats /tmp/prof/stats64 $OUT/kernel_stats_64x64x3.csv
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof/mfma64 -o r -- python3 $R/bench.py --steps 3 --warmup 2 --no-graph $B64 > /tmp/prof/mfma64.out 2> /tmp/prof/mfma64.err
+python3 $R/tools/profile_summary.py mfma /tmp/prof/mfma64 /tmp/prof/stats64 $OUT/mfma_util_64x64x3.json
 ls -la $OUT
