@@ -34,6 +34,7 @@ struct GnArgs {
     float* dbeta_part;             // backward, swish / hardswish: [N][C] per image and channel sums of dy * mask * d act / d scalar
     float* scratch;                // split path: partial sums of the pixel splits
     int P, rows_per_split;         // split path: pixel splits per (image, slab) and pixels per split
+    int fixed;                     // statistics are given (stats is an input of the forward pass, a constant of the backward pass)
 };
 
 // NV = vectors a thread keeps in registers when the whole slab fits (NV > 0): the slab is then read from memory
@@ -74,7 +75,15 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
             if (p < a.HW) xv[k] = *(const bf16x8*)(a.x + base + (long long)p * a.C);
         }
     }
-    if (a.G > 0) {
+    if (a.G > 0 && a.fixed) {
+        const int ngrp = a.SC / cpg;
+        if (tid < ngrp) {
+            const int g = c0 / cpg + tid;
+            s_mean[tid] = a.stats[((long long)n * a.G + g) * 2 + 0];
+            s_rstd[tid] = a.stats[((long long)n * a.G + g) * 2 + 1];
+        }
+        __syncthreads();
+    } else if (a.G > 0) {
         float s[8], ss[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int g = (cv * 8 + j) / cpg;
-            S1[j] = s_s1[g]; S2[j] = s_s2[g];
+            S1[j] = a.fixed ? 0.f : s_s1[g]; S2[j] = a.fixed ? 0.f : s_s2[g];
         }
     }
     float db[8];
@@ -394,7 +403,11 @@ __global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a
     const int cpg = a.G > 0 ? a.C / a.G : 1;
     if (a.G > 0) {
         const int ngrp = a.SC / cpg;
-        if (tid < ngrp) {
+        if (tid < ngrp && a.fixed) {
+            const int g = c0 / cpg + tid;
+            s_mean[tid] = a.stats[((long long)n * a.G + g) * 2 + 0];
+            s_rstd[tid] = a.stats[((long long)n * a.G + g) * 2 + 1];
+        } else if (tid < ngrp) {
             const int g = c0 / cpg + tid;
             const float* in = a.scratch + ((long long)n * a.G + g) * a.P * 2;
             float S = 0.f, SS = 0.f;
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a
                 const float ga = a.gamma[c0 + tid * cpg + c];
                 u += s_a1[tid * cpg + c] * ga; v += s_a2[tid * cpg + c] * ga;
             }
-            const float im = 1.0f / (float)(cpg * a.HW);
+            const float im = a.fixed ? 0.f : 1.0f / (float)(cpg * a.HW);
             s_s1[tid] = u * im; s_s2[tid] = v * im;
         }
         __syncthreads();
@@ -638,6 +651,8 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     DDPM_REQUIRE(!ACT_HAS_BETA(d->act) || d->act_beta, "%s: swish / hardswish need their scalar (act_beta)", what);
     a.act_beta = d->act_beta; a.dbeta_part = d->dbeta_part;
     a.scratch = d->scratch; a.P = 0; a.rows_per_split = 0;
+    a.fixed = d->fixed_stats != 0;
+    DDPM_REQUIRE(!a.fixed || (d->G > 0 && d->stats), "%s: fixed_stats needs groups and the stats tensor", what);
     return DDPM_OK;
 }
 
@@ -690,7 +705,7 @@ extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_)
     if (int rc = gn_prepare(a, d, "gn_forward")) return rc;
     if (gn_use_split(a, d, false)) {
         const int units = a.N * (a.C / a.SC) * a.P;
-        if (a.G > 0) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        if (a.G > 0 && !a.fixed) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
         hipLaunchKernelGGL(gn_fwd_split_apply_kernel, dim3(units), dim3(GS_T), 0, stream, a);
         return ddpm_check_launch("gn_forward");
     }
@@ -767,10 +782,54 @@ extern "C" int ddpm_gn_act_forward_static(const ddpm_gn_desc* d, ddpm_stream_t s
         // every partial-sum slot the apply launch reads is written by the statistics launch before it: nothing in the
         // workspace has to start at zero, whatever an earlier (larger) call left there
         const int units = a.N * (a.C / a.SC) * a.P;
-        if (a.G > 0) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        if (a.G > 0 && !a.fixed) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
         hipLaunchKernelGGL(gn_fwd_split_apply_kernel, dim3(units), dim3(GS_T), 0, stream, a);
         return ddpm_check_launch("gn_forward_static");
     }
     GN_DISPATCH(gn_fwd_kernel)
     return ddpm_check_launch("gn_forward_static");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm2d in training mode is the GroupNorm above on the tensor viewed as ONE image of N*H*W pixels with one group per
+// channel (statistics per channel over batch and space; torch.nn.BatchNorm2d as used by the autoencoder blocks,
+// neural_nets/autoencoders/constituent_blocks.py:67,85,160,178 and base_ae.py:192 of the reference).  What remains is the
+// module's running-statistics update: running = (1 - momentum) running + momentum * batch value, the variance unbiased
+// (count / (count - 1)), and the batch counter.
+__global__ __launch_bounds__(256) void bn_update_running_kernel(const float* __restrict__ stats, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, long long* __restrict__ num_batches,
+                                                                 int C, float count, float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        const float mean = stats[c * 2], rstd = stats[c * 2 + 1];
+        const float var = fmaxf(1.0f / (rstd * rstd) - eps, 0.f);
+        const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (c == 0 && num_batches) *num_batches += 1;
+}
+
+extern "C" int ddpm_bn_update_running(const float* stats, float* running_mean, float* running_var, int64_t* num_batches, int C,
+                                      int64_t count, float momentum, float eps, ddpm_stream_t stream_) {
+    DDPM_REQUIRE(stats && running_mean && running_var && C > 0 && count > 0, "bn_update_running: bad arguments");
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, stats, running_mean, running_var,
+                       (long long*)num_batches, C, (float)count, momentum, eps);
+    return ddpm_check_launch("bn_update_running");
+}
+
+// stats[c] = (running_mean[c], rsqrt(running_var[c] + eps)): what the forward pass takes as fixed statistics in eval mode
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                             float* __restrict__ stats, int C, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        stats[c * 2] = running_mean[c];
+        stats[c * 2 + 1] = rsqrtf(running_var[c] + eps);
+    }
+}
+
+extern "C" int ddpm_bn_eval_stats(const float* running_mean, const float* running_var, float* stats, int C, float eps, ddpm_stream_t stream_) {
+    DDPM_REQUIRE(stats && running_mean && running_var && C > 0, "bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, running_mean, running_var, stats, C, eps);
+    return ddpm_check_launch("bn_eval_stats");
 }

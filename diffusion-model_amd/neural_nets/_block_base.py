@@ -15,6 +15,7 @@ from ..utils.initializers import get_initializer
 from .activations import activation_code, has_scalar
 
 W_INIT, ONES, ZEROS, LINEAR_BIAS_DEFAULT = range(4)
+BUF_ZEROS, BUF_ONES, BUF_COUNT = "buffer:zeros", "buffer:ones", "buffer:count"      # BatchNorm2d's registered buffers
 BF16 = torch.bfloat16
 
 
@@ -35,10 +36,14 @@ class BlockSpec:
 class _Slot(nn.Module):
     """Parameter container addressed by dotted paths ('layers.1.expansion.1.weight')."""
 
-    def put(self, path: str, p: nn.Parameter) -> None:
+    def put(self, path: str, p) -> None:
+        """p: an nn.Parameter, or a plain tensor to be registered as a buffer"""
         head, _, rest = path.partition(".")
         if not rest:
-            self.register_parameter(head, p)
+            if isinstance(p, nn.Parameter):
+                self.register_parameter(head, p)
+            else:
+                self.register_buffer(head, p)
             return
         if head not in self._modules:
             self.add_module(head, _Slot())
@@ -67,6 +72,7 @@ class _BlockFn(torch.autograd.Function):
         inputs, flat_params = tensors[:n_in], tensors[n_in:]
         eng = module._get_engine()
         params = dict(zip(module._param_names, flat_params))
+        params.update(module.named_buffers())          # BatchNorm2d statistics: read (and, in training mode, advanced) by the kernels
         ctx.set_materialize_grads(False)
         kin = [module._to_kernel(t) for t in inputs]
         key = (module.__class__.__name__,) + tuple(tuple(t.shape) for t in kin)
@@ -96,6 +102,14 @@ class BlockModule(nn.Module):
         self._spec = spec
         names = []
         for name, shape, rule in table:
+            if rule in (BUF_ZEROS, BUF_ONES, BUF_COUNT):
+                t = (torch.zeros(shape, device=device, dtype=torch.long) if rule == BUF_COUNT else
+                     torch.full(shape, 1.0 if rule == BUF_ONES else 0.0, device=device, dtype=torch.float32))
+                head, _, rest = name.partition(".")
+                if head not in self._modules:
+                    self.add_module(head, _Slot())
+                self._modules[head].put(rest, t)
+                continue
             t = torch.empty(shape, device=device, dtype=torch.float32)
             if callable(rule):
                 rule(t)
@@ -158,6 +172,12 @@ def conv_entries(name: str, co: int, ci: int, k: int):
 
 def norm_entries(name: str, c: int):
     return [(name + ".weight", (c,), ONES), (name + ".bias", (c,), ZEROS)]
+
+
+def bn_entries(name: str, c: int) -> list:
+    """torch.nn.BatchNorm2d(c): weight = 1, bias = 0 and the buffers running_mean = 0, running_var = 1, num_batches_tracked = 0"""
+    return norm_entries(name, c) + [(name + ".running_mean", (c,), BUF_ZEROS), (name + ".running_var", (c,), BUF_ONES),
+                                    (name + ".num_batches_tracked", (), BUF_COUNT)]
 
 
 def act_entries(site: str, activation: str) -> list:

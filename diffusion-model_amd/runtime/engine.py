@@ -22,7 +22,10 @@ import torch
 from torch import Tensor
 
 from . import hip, ops, pack
-from .params import GradStore, WeightCache
+from .params import GradStore, WeightCache, conv_dims
+
+# state_dict entries that are buffers of a BatchNorm2d, not parameters: they travel with the parameters but have no gradient
+BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
 
 BF16 = torch.bfloat16
 K33, K33S2, K11, KT22 = hip.CONV_3X3_S1, hip.CONV_3X3_S2, hip.CONV_1X1, hip.CONVT_2X2_S2
@@ -274,7 +277,8 @@ class UNetEngine:
         self.wc.refresh(params, dev, force=self.always_repack)
         if record:
             if self.grads is None or self.grads.flat.device != dev:
-                self.grads = GradStore(sp.convs, sp.dwconvs, params, dev, getattr(sp, "aliases", None))
+                self.grads = GradStore(sp.convs, sp.dwconvs, {k: v for k, v in params.items() if not k.endswith(BUFFER_SUFFIXES)}, dev,
+                                       getattr(sp, "aliases", None))
         tape: Optional[List[Callable[[], None]]] = [] if record else None
         use_drop = train and sp.drop_p > 0.0
         if use_drop and masks is None:
@@ -467,6 +471,61 @@ class UNetEngine:
                     c1 = x1.v.shape[3]
                     x1.g = ops.conv_forward(dk, draw, wd, None, c1, res=x1.g, row0=c0, rows=c1)
             return bwd
+
+        def conv_bn_unit(name: str, x0: Var, bn: str, act: int) -> Var:
+            """bias-free conv -> BatchNorm2d -> act, the unit of the autoencoder blocks (autoencoders/constituent_blocks.py:58-68,
+            77-86,151-161,170-179; base_ae.py:184-193 of the reference).  Training mode normalises with batch statistics and
+            advances the module's running statistics; eval mode normalises with the running statistics."""
+            kind = sp.convs[name]
+            cout = conv_dims(kind, P[name + ".weight"])[0]
+            raw = ops.conv_forward(kind, x0.v, wc.fwd[name], None, cout)
+            site = act_site(bn)
+            bsc = act_scalar(site, act)
+            gamma, beta = P[bn + ".weight"], P[bn + ".bias"]
+            y, stats = ops.batchnorm_act_forward(raw, gamma, beta, act, training=train, running_mean=P[bn + ".running_mean"],
+                                                 running_var=P[bn + ".running_var"], num_batches=P.get(bn + ".num_batches_tracked"),
+                                                 act_beta=bsc)
+            out = Var(y)
+            if tape is not None:
+                def bwd():
+                    buf, off = part_alloc(3 * cout)             # complete sums: the whole batch is one 'image' of the norm kernel
+                    part_entries.append((off, G.offset(bn + ".weight"), 1, 3 * cout, cout))
+                    part_entries.append((off + cout, G.offset(bn + ".bias"), 1, 3 * cout, cout))
+                    draw = ops.batchnorm_act_backward(raw, out.g, gamma, beta, act, stats, buf, training=train, act_beta=bsc,
+                                                      dbeta_part=None if bsc is None else scalar_partials(site, cout))
+                    out.g = None
+                    wgrad(kind, x0.v, draw, cout, name)
+                    if x0.need_grad:
+                        x0.g = ops.conv_forward(pack.DGRAD_KIND[kind], draw, wc.dgrad[name], None, x0.v.shape[3], res=x0.g)
+                tape.append(bwd)
+            return out
+
+        def head_unit(name: str, x0: Var, act: int = 0) -> Var:
+            """conv -> [tanh] -> NCHW fp32: a network's image head (at most 16 output channels)"""
+            kind = sp.convs[name]
+            bias = P.get(name + ".bias")
+            cout = conv_dims(kind, P[name + ".weight"])[0]
+            if cout > 16 or act not in (0, hip.ACT["tanh"]):
+                raise ValueError("head_unit: at most 16 output channels, activation none or tanh")
+            y = ops.conv_forward(kind, x0.v, wc.fwd[name], bias, cout, act=act, f32_nchw=True)
+            out = Var(y)
+            if tape is not None:
+                def bwd():
+                    n_, _, oh, ow = y.shape
+                    dz = torch.empty(n_, oh, ow, 16, device=dev, dtype=BF16)
+                    dy = out.g.contiguous()
+                    if act:
+                        hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(y), hip.ptr(dz), n_, cout, oh * ow, 16, hip.stream())
+                    else:
+                        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(dy), hip.ptr(dz), n_, cout, oh * ow, 16, hip.stream())
+                    if bias is not None:
+                        ops.colsum(dz, G[name + ".bias"], cout)
+                    wgrad(kind, x0.v, dz, cout, name)
+                    if x0.need_grad:
+                        x0.g = ops.conv_forward(pack.DGRAD_KIND[kind], dz, wc.dgrad[name], None, x0.v.shape[3], res=x0.g,
+                                                c0_used=cout if cout <= 4 else 0)
+                tape.append(bwd)
+            return out
 
         def dw_unit(pre: str, xin: Var, out_mask) -> Var:
             """depthwise 3x3 -> GroupNorm -> act [-> * out_mask]   (conv_block.py:77-96)"""
@@ -709,7 +768,7 @@ class UNetEngine:
 
         from types import SimpleNamespace
         return SimpleNamespace(P=P, G=G, wc=wc, tape=tape, conv_unit=conv_unit, conv_bwd=conv_bwd, dw_unit=dw_unit, sir=sir, embed=embed,
-                               attn_module=attn_module,
+                               attn_module=attn_module, conv_bn_unit=conv_bn_unit, head_unit=head_unit,
                                wgrad=wgrad, part_alloc=part_alloc, part_entries=part_entries, gn_partials=gn_partials, tap=tap, late=late,
                                finish=flush, mscale=mscale)
 

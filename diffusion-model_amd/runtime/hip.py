@@ -44,7 +44,7 @@ class GnDesc(C.Structure):
         ("x", _vp), ("gamma", _vp), ("beta", _vp), ("res", _vp), ("mask", _vp), ("mask_scale", _f),
         ("y", _vp), ("stats", _vp), ("dy", _vp), ("part", _vp),
         ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f), ("scratch", _vp), ("scratch_floats", _i64),
-        ("act_beta", _vp), ("dbeta_part", _vp),
+        ("act_beta", _vp), ("dbeta_part", _vp), ("fixed_stats", _i),
     ]
 
 
@@ -131,6 +131,8 @@ _PROTOS = {
     "ddpm_gn_scratch_floats": ([C.POINTER(GnDesc), _i], _i64),
     "ddpm_gn_act_forward_static": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_static_scratch_floats": ([], _i64),
+    "ddpm_bn_update_running": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp], _i),
+    "ddpm_bn_eval_stats": ([_vp, _vp, _vp, _i, _f, _vp], _i),
     "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),

@@ -183,9 +183,11 @@ def _gn_scratch(d, backward: int, device) -> Optional[Tensor]:
 
 def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int, *,
                    res: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
-                   stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5, act_beta: Optional[Tensor] = None):
+                   stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5, act_beta: Optional[Tensor] = None,
+                   fixed_stats: bool = False):
     """x: NHWC bf16.  Returns (y, stats) with stats fp32 [N][G][2] (None when groups == 0).  act_beta: the activation's
-    learnable scalar (a device fp32 tensor with one element), required for swish / hardswish."""
+    learnable scalar (a device fp32 tensor with one element), required for swish / hardswish.  fixed_stats: normalise with
+    the (mean, rstd) pairs given in `stats` instead of computing them."""
     n, h, w, c = x.shape
     assert x.dtype == BF16 and x.is_contiguous()
     if out is None:
@@ -194,7 +196,7 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
         stats = torch.empty(n, groups, 2, device=x.device, dtype=torch.float32)
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=None, part=None, N=n, HW=h * w, C=c, G=groups,
-                   act=act, eps=eps, act_beta=_scalar_ptr(act, act_beta))
+                   act=act, eps=eps, act_beta=_scalar_ptr(act, act_beta), fixed_stats=int(fixed_stats))
     scratch = _gn_scratch(d, 0, x.device)
     _launch("gn_fwd_split_kernel" if scratch is not None else "gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream()))
@@ -204,7 +206,7 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
 def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int,
                     stats: Optional[Tensor], part: Tensor, *, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
                     out: Optional[Tensor] = None, eps: float = 1e-5, act_beta: Optional[Tensor] = None,
-                    dbeta_part: Optional[Tensor] = None) -> Tensor:
+                    dbeta_part: Optional[Tensor] = None, fixed_stats: bool = False) -> Tensor:
     """Returns dx.  part: fp32 [N][3][C] receives per-image partial sums (dgamma, dbeta, bias gradient).  swish / hardswish:
     act_beta = the activation's scalar, dbeta_part = fp32 [N][C] that receives the partial sums of the scalar's gradient."""
     n, h, w, c = x.shape
@@ -214,12 +216,40 @@ def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Option
         out = torch.empty_like(x)
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=None, mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=hip.ptr(dy), part=hip.ptr(part), N=n, HW=h * w, C=c, G=groups, act=act,
-                   eps=eps, act_beta=_scalar_ptr(act, act_beta), dbeta_part=hip.ptr(dbeta_part))
+                   eps=eps, act_beta=_scalar_ptr(act, act_beta), dbeta_part=hip.ptr(dbeta_part), fixed_stats=int(fixed_stats))
     assert act not in hip.ACT_WITH_SCALAR or (dbeta_part is not None and dbeta_part.numel() == n * c and dbeta_part.dtype == torch.float32)
     scratch = _gn_scratch(d, 1, x.device)
     _launch("gn_bwd_split_kernel" if scratch is not None else "gn_bwd_kernel", lambda: (_nb(x, dy, mask, out, gamma, beta, stats, part), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_backward", C.byref(d), hip.stream()))
     return out
+
+
+def batchnorm_act_forward(x: Tensor, gamma: Tensor, beta: Tensor, act: int, *, training: bool, running_mean: Tensor, running_var: Tensor,
+                          num_batches: Optional[Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, act_beta: Optional[Tensor] = None):
+    """act(BatchNorm2d(x)) on NHWC bf16 (torch.nn.BatchNorm2d semantics).  Training: batch statistics per channel over
+    N*H*W - the GroupNorm kernels on the tensor described as one image of N*H*W pixels with one group per channel - and
+    the running statistics advance; eval: the running statistics are the (fixed) statistics.  Returns (y, stats [1][C][2])."""
+    n, h, w, c = x.shape
+    xv = x.view(1, n * h * w, 1, c)
+    if training:
+        y, stats = gn_act_forward(xv, gamma, beta, c, act, eps=eps, act_beta=act_beta)
+        hip.call("ddpm_bn_update_running", hip.ptr(stats), hip.ptr(running_mean), hip.ptr(running_var), hip.ptr(num_batches), c, n * h * w,
+                 float(momentum), float(eps), hip.stream())
+    else:
+        stats = torch.empty(1, c, 2, device=x.device, dtype=torch.float32)
+        hip.call("ddpm_bn_eval_stats", hip.ptr(running_mean), hip.ptr(running_var), hip.ptr(stats), c, float(eps), hip.stream())
+        y, _ = gn_act_forward(xv, gamma, beta, c, act, eps=eps, act_beta=act_beta, stats=stats, fixed_stats=True)
+    return y.view(n, h, w, c), stats
+
+
+def batchnorm_act_backward(x: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, act: int, stats: Tensor, part: Tensor, *, training: bool,
+                           eps: float = 1e-5, act_beta: Optional[Tensor] = None, dbeta_part: Optional[Tensor] = None) -> Tensor:
+    """Gradient w.r.t. x of the above.  part: fp32 [3][C] receives d gamma, d beta and the column sums of dx (complete sums: the
+    whole batch is one 'image' here); dbeta_part: fp32 [C] for the swish / hardswish scalar."""
+    n, h, w, c = x.shape
+    dx = gn_act_backward(x.view(1, n * h * w, 1, c), dy.view(1, n * h * w, 1, c), gamma, beta, c, act, stats, part, eps=eps, act_beta=act_beta,
+                         dbeta_part=dbeta_part, fixed_stats=not training)
+    return dx.view(n, h, w, c)
 
 
 def _scalar_ptr(act: int, beta: Optional[Tensor]):

@@ -189,6 +189,8 @@ typedef struct ddpm_gn_desc {
     float* dbeta_part;        /* backward, swish / hardswish: fp32 [N][C], written once: per image and channel sums of
                                * dy * mask * d act / d b.  The scalar's gradient is the sum of all N*C entries
                                * (ddpm_reduce_rows entry with scalar = 1). */
+    int fixed_stats;          /* 1: `stats` holds the statistics to normalise with (forward computes none; backward treats them
+                               * as constants): BatchNorm2d in eval mode */
 } ddpm_gn_desc;
 
 /* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:
@@ -207,6 +209,15 @@ int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward);
  * (different streams) race; calls on one stream, or ordered by events, do not. */
 int ddpm_gn_act_forward_static(const ddpm_gn_desc* d, ddpm_stream_t stream);
 int64_t ddpm_gn_static_scratch_floats(void);
+
+/* torch.nn.BatchNorm2d of the autoencoder blocks (neural_nets/autoencoders/constituent_blocks.py:67,85,160,178; base_ae.py:192).
+ * Training mode IS ddpm_gn_act_forward / _backward on the tensor described as one image of N*H*W pixels with G = C groups
+ * (statistics per channel over batch and space); stats then holds [C][2] = (batch mean, rstd).  These two calls complete the
+ * module: the running-statistics update of a training step (momentum rule, unbiased variance, batch counter; num_batches may be
+ * NULL), and the [C][2] statistics an eval-mode pass normalises with (pass them with fixed_stats = 1). */
+int ddpm_bn_update_running(const float* stats, float* running_mean, float* running_var, int64_t* num_batches, int C, int64_t count,
+                           float momentum, float eps, ddpm_stream_t stream);
+int ddpm_bn_eval_stats(const float* running_mean, const float* running_var, float* stats, int C, float eps, ddpm_stream_t stream);
 
 /* ---- depthwise 3x3 convolution, stride 1, padding 1, NHWC bf16 (dwconv.hip) ---------------------- */
 

@@ -542,3 +542,80 @@ def hash_params(cfg: UNetCfg, seed: int = 1, prefix: str = "model.", residual_ga
         if k.endswith("out_layers.2.weight"):
             p[k] = p[k] * head_gain
     return p
+
+
+# --------------------------------------------------------------------------- autoencoder blocks (latent-diffusion configuration)
+def batch_norm(p: Params, pre: str, x: Tensor, training: bool, momentum: float = 0.1, eps: float = 1e-5) -> Tensor:
+    """torch.nn.BatchNorm2d.forward: batch statistics in training mode (the running statistics p[pre + 'running_*'] advance
+    in place and the batch counter increments), the running statistics in eval mode."""
+    if training and pre + "num_batches_tracked" in p:
+        p[pre + "num_batches_tracked"] += 1
+    return F.batch_norm(x, p[pre + "running_mean"], p[pre + "running_var"], p[pre + "weight"], p[pre + "bias"], training, momentum, eps)
+
+
+def _conv_bn_act(p: Params, conv: str, bn: str, site: str, x: Tensor, act, training: bool, *, stride=1, padding=1, transposed=False) -> Tensor:
+    if transposed:
+        y = F.conv_transpose2d(x, _r(p[conv + "weight"]), None, stride=2)
+    else:
+        y = F.conv2d(x, _r(p[conv + "weight"]), None, stride=stride, padding=padding)
+    return _r(act(batch_norm(p, bn, _r(y), training), site))
+
+
+def ae_down_block(p: Params, pre: str, x: Tensor, act, drop: DropMasks, training: bool) -> Tensor:
+    """autoencoders/constituent_blocks.py:56-88,100-114: conv3x3 s2 (no bias) + BatchNorm2d + act -> inverted residual ->
+    conv3x3 (no bias) + BatchNorm2d + act"""
+    z = _conv_bn_act(p, pre + "layers.0.", pre + "layers.1.", pre + "layers.2", x, act, training, stride=2)
+    z = sir_block(p, pre + "layers.3.", z, 16, act, drop)
+    return _conv_bn_act(p, pre + "layers.4.", pre + "layers.5.", pre + "layers.6", z, act, training)
+
+
+def ae_up_block(p: Params, pre: str, x: Tensor, act, drop: DropMasks, training: bool) -> Tensor:
+    """autoencoders/constituent_blocks.py:150-181,193-198: convT 2x2 s2 (no bias) + BatchNorm2d + act -> inverted residual ->
+    conv3x3 (no bias) + BatchNorm2d + act"""
+    z = _conv_bn_act(p, pre + "layers.0.", pre + "layers.1.", pre + "layers.2", x, act, training, transposed=True)
+    z = sir_block(p, pre + "layers.3.", z, 16, act, drop)
+    return _conv_bn_act(p, pre + "layers.4.", pre + "layers.5.", pre + "layers.6", z, act, training)
+
+
+def ae_encoder(p: Params, x: Tensor, n_stages: int, act, drop: DropMasks, training: bool) -> Tensor:
+    """base_ae.py:81-114: conv3x3 + act, then one DownBlock per stage"""
+    z = _r(act(_r(F.conv2d(_r(x), _r(p["layers.0.0.weight"]), p["layers.0.0.bias"], padding=1)), "layers.0.1"))
+    for i in range(n_stages):
+        z = ae_down_block(p, f"layers.{i + 1}.", z, act, drop, training)
+    return z
+
+
+def ae_decoder(p: Params, z: Tensor, n_stages: int, act, drop: DropMasks, training: bool) -> Tensor:
+    """base_ae.py:173-248: convT 2x2 s2 + act -> conv1x1 (no bias) + BatchNorm2d + act -> UpBlocks -> conv3x3 + act + conv3x3"""
+    z = _r(act(_r(F.conv_transpose2d(_r(z), _r(p["layers.0.weight"]), p["layers.0.bias"], stride=2)), "layers.1"))
+    z = _conv_bn_act(p, "layers.2.", "layers.3.", "layers.4", z, act, training, padding=0)
+    for i in range(n_stages):
+        z = ae_up_block(p, f"layers.{5 + i}.", z, act, drop, training)
+    last = f"layers.{5 + n_stages}."
+    z = _r(act(_r(F.conv2d(z, _r(p[last + "0.weight"]), p[last + "0.bias"], padding=1)), last + "1"))
+    return F.conv2d(z, _r(p[last + "2.weight"]), p[last + "2.bias"], padding=1)
+
+
+def hash_state(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Params:
+    """Deterministic values for a state_dict given as {key: shape} (parameters and BatchNorm buffers alike): weights of
+    convolutions / linears ~ U(+-sqrt(3 / fan_in)), norm weights and activation scalars 1 +- 0.3, running variances 1 +- 0.3,
+    biases and running means ~ U(+-0.2), batch counters 0."""
+    p: Params = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        shp = tuple(shp)
+        if k.endswith("num_batches_tracked"):
+            p[k] = torch.zeros((), dtype=torch.long)
+        elif len(shp) >= 2:
+            fan_in = 1
+            for dd in shp[1:]:
+                fan_in *= dd
+            if len(shp) == 4 and shp[2] == 2:                 # ConvTranspose2d (in, out, 2, 2)
+                fan_in = shp[0]
+            p[k] = hash_fill(shp, seed * 1000 + i, math.sqrt(3.0 / fan_in))
+        elif k.endswith(".beta"):
+            p[k] = hash_fill((1,), seed * 1000 + i, 0.3, 1.0).reshape(())
+        elif k.endswith("running_var") or k.endswith("weight"):
+            p[k] = hash_fill(shp, seed * 1000 + i, 0.3, 1.0)
+        else:
+            p[k] = hash_fill(shp, seed * 1000 + i, 0.2)
+    return p

@@ -173,3 +173,23 @@ def test_sample_bytes_truncate_like_to_pil_image(golden):
     assert got.dtype == torch.uint8 and torch.equal(got, want)
     x = torch.tensor([[-1.0, -0.999, 0.0, 0.5, 0.9999, 1.0, 3.0]])
     assert dm_ddpm.DDPM.to_uint8(x).tolist() == [[0, 0, 127, 191, 254, 255, 255]]
+
+
+def test_autoencoder_modules_expose_the_reference_keys(golden):
+    """The autoencoder blocks register the reference's parameters AND BatchNorm2d buffers under its state_dict keys, in its
+    order, with its shapes (the fixture's shape tables were read off the reference modules, tools/gen_golden.py)."""
+    from dm_amd.neural_nets.autoencoders import Decoder, DownBlock as AeDown, Encoder, UpBlock as AeUp
+    g = golden("autoencoder.pt")
+    for act in ("gelu", "hardswish"):
+        kw = dict(expand_factor=2, drop_p=0.0, activation=act, initializer="he_uniform")
+        for mod, tag in ((AeDown(32, 64, **kw), f"down.{act}"), (AeUp(64, 32, **kw), f"up.{act}")):
+            sd = mod.state_dict()
+            assert list(sd) == list(g[tag]["shapes"]) and all(tuple(v.shape) == tuple(g[tag]["shapes"][k]) for k, v in sd.items())
+            assert sd["layers.1.num_batches_tracked"].dtype == torch.long and float(sd["layers.1.running_var"][0]) == 1.0
+            assert [k for k, _ in mod.named_parameters()] == list(g[tag]["gdigest"])
+    kw = dict(expand_factor=2, drop_p=0.0, activation="hardswish", initializer="he_uniform")
+    for mod, tag in ((Encoder(3, (64, 128), 128, **kw), "encoder.hardswish"), (Decoder(3, 128, (128, 64), **kw), "decoder.hardswish")):
+        sd = mod.state_dict()
+        assert list(sd) == list(g[tag]["shapes"]) and all(tuple(v.shape) == tuple(g[tag]["shapes"][k]) for k, v in sd.items())
+    with pytest.raises(ValueError):
+        Encoder(3, (16, 24), 24, 2)          # the widths of the reference's stale dict config do not fit the MFMA kernels

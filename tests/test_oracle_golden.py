@@ -237,3 +237,45 @@ def test_learnable_scalar_activations(golden, act):
         _digest_close(grads[k], d, 2e-3)
     for k, v in u["beta_grads"].items():
         close(grads[k], v, 2e-3, 1e-6)
+
+
+def _ae_run(kind, rec, act_name, training=True):
+    p = O.hash_state(rec["shapes"], rec["seed"])
+    leaves = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p.items()}
+    act = O.act_fn(act_name, leaves)
+    x = rec["x"].clone().requires_grad_(True)
+    fn = {"down": lambda: O.ae_down_block(leaves, "", x, act, O.DropMasks(), training),
+          "up": lambda: O.ae_up_block(leaves, "", x, act, O.DropMasks(), training),
+          "encoder": lambda: O.ae_encoder(leaves, x, 2, act, O.DropMasks(), training),
+          "decoder": lambda: O.ae_decoder(leaves, x, 2, act, O.DropMasks(), training)}[kind]
+    return fn(), x, leaves
+
+
+@pytest.mark.parametrize("tag", ["down.gelu", "down.hardswish", "up.gelu", "up.hardswish", "encoder.hardswish", "decoder.hardswish"])
+def test_autoencoder_blocks(golden, tag):
+    """The autoencoder Down/Up blocks and Encoder / Decoder stacks of the reference (bias-free convolutions + BatchNorm2d +
+    activation around an inverted-residual block): training-mode output, all gradients, the advanced running statistics,
+    and the eval-mode output computed with them."""
+    rec = golden("autoencoder.pt")[tag]
+    kind, act_name = tag.split(".")
+    y, x, leaves = _ae_run(kind, rec, act_name)
+    close(y, rec["y"], 2e-4, 2e-5)
+    names = [k for k, v in leaves.items() if v.requires_grad]
+    assert names == list(rec["gdigest"])
+    grads = torch.autograd.grad(y, [x] + [leaves[k] for k in names], hash_normal(tuple(y.shape), rec["gy_seed"]))
+    close(grads[0], rec["gx"], 2e-3, 2e-4)
+    for k, g in zip(names, grads[1:]):
+        _digest_close(g, rec["gdigest"][k], 5e-3)
+        if rec["gparams"][k] is not None:
+            close(g, rec["gparams"][k], 5e-3, 5e-4)
+    for k, v in rec["buffers_after"].items():
+        close(leaves[k].detach(), v, 1e-5, 1e-6) if v.dtype.is_floating_point else None
+        assert v.dtype.is_floating_point or int(leaves[k]) == int(v) == 1
+    # eval mode with the statistics the training step left behind
+    with torch.no_grad():
+        p = dict(O.hash_state(rec["shapes"], rec["seed"]), **rec["buffers_after"])
+        act = O.act_fn(act_name, p)
+        xe = rec["x"]
+        ye = {"down": lambda: O.ae_down_block(p, "", xe, act, O.DropMasks(), False), "up": lambda: O.ae_up_block(p, "", xe, act, O.DropMasks(), False),
+              "encoder": lambda: O.ae_encoder(p, xe, 2, act, O.DropMasks(), False), "decoder": lambda: O.ae_decoder(p, xe, 2, act, O.DropMasks(), False)}[kind]()
+    close(ye, rec["y_eval"], 2e-4, 2e-5)

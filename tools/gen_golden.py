@@ -377,8 +377,64 @@ def gen_beta_activations():
     save("beta_activations.pt", out)
 
 
+def _load_reference_autoencoders():
+    """The reference's autoencoder classes.  Its package neural_nets/autoencoders/__init__.py imports a module that does not
+    exist, so the two source files are loaded by file path under their own dotted names (the package entry is an empty
+    namespace that only carries the directory)."""
+    import importlib.util
+    base = os.path.join(REF, "neural_nets", "autoencoders")
+    pkg = types.ModuleType("neural_nets.autoencoders")
+    pkg.__path__ = [base]
+    sys.modules["neural_nets.autoencoders"] = pkg
+    mods = {}
+    for name in ("constituent_blocks", "base_ae"):
+        full = f"neural_nets.autoencoders.{name}"
+        spec = importlib.util.spec_from_file_location(full, os.path.join(base, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods["constituent_blocks"], mods["base_ae"]
+
+
+def _ae_record(mod, seed, x, gy_seed, small=4096):
+    """state from oracle.hash_state over the module's own state_dict shapes; one training-mode forward + backward (batch
+    statistics, running statistics advance), then an eval-mode forward with the advanced statistics"""
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(O.hash_state(shapes, seed))
+    mod.train()
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = hash_normal(tuple(y.shape), gy_seed)
+    names = [k for k, _ in mod.named_parameters()]
+    grads = torch.autograd.grad(y, [xr] + list(mod.parameters()), gy)
+    rec = {"shapes": shapes, "seed": seed, "x": x, "y": y.detach(), "gy_seed": gy_seed, "gx": grads[0],
+           "gparams": {k: (g if g.numel() <= small else None) for k, g in zip(names, grads[1:])},
+           "gdigest": {k: grad_digest(g) for k, g in zip(names, grads[1:])},
+           "buffers_after": {k: v.clone() for k, v in mod.named_buffers()}}
+    mod.eval()
+    with torch.no_grad():
+        rec["y_eval"] = mod(x)
+    return rec
+
+
+def gen_autoencoder():
+    """The autoencoder side of the latent-diffusion configuration: Down/Up blocks (bias-free convolutions, BatchNorm2d) and the
+    Encoder / Decoder stacks, at channel counts the MFMA kernels take (the reference's own dict configs for them are stale)."""
+    blocks, base = _load_reference_autoencoders()
+    out = {}
+    for act in ("gelu", "hardswish"):
+        kw = dict(expand_factor=2, drop_p=0.0, activation=act, initializer="he_uniform")
+        out[f"down.{act}"] = _ae_record(blocks.DownBlock(32, 64, **kw), 11, hash_normal((2, 32, 8, 8), 61), 62)
+        out[f"up.{act}"] = _ae_record(blocks.UpBlock(64, 32, **kw), 12, hash_normal((2, 64, 4, 4), 63), 64)
+    kw = dict(expand_factor=2, drop_p=0.0, activation="hardswish", initializer="he_uniform")
+    out["encoder.hardswish"] = _ae_record(base.Encoder(3, (64, 128), 128, **kw), 13, hash_uniform((2, 3, 16, 16), 65) * 2 - 1, 66)
+    out["decoder.hardswish"] = _ae_record(base.Decoder(3, 128, (128, 64), **kw), 14, hash_normal((2, 128, 2, 2), 67), 68)
+    save("autoencoder.pt", out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_schedule_and_ops, gen_blocks, gen_unet_full, gen_sample_chain, gen_conditional, gen_beta_activations):
+    for fn in (gen_schedule_and_ops, gen_blocks, gen_unet_full, gen_sample_chain, gen_conditional, gen_beta_activations, gen_autoencoder):
         if not only or fn.__name__ in only:
             fn()
