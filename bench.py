@@ -135,7 +135,8 @@ def timed(step_fn, steps, warmup, barrier, dist, dev):
 
 def extra_configs(dev, world, dist, barrier, reducer_factory, use_graph):
     """The other GPU configs BASELINE.json names, same code, shorter runs: Flowers102-shaped 64x64x3 training (batch 128 per
-    GPU, data parallel when N > 1) and 128x128x3 sampling with self-attention at the 16x16 stage (128 images per GPU)."""
+    GPU, data parallel when N > 1), 128x128x3 sampling with self-attention at the 16x16 stage (128 images per GPU) and latent
+    diffusion on 256x256x3 images (autoencoder + the same denoiser on the latents)."""
     out = {}
     # -- 64x64x3 training
     m = build_model(dev, 3)
@@ -164,6 +165,38 @@ def extra_configs(dev, world, dist, barrier, reducer_factory, use_graph):
     out["sample_128x128x3_attention"] = {"value": nb * world / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / 120, "batch_per_gpu": nb,
                                          "n_gpus": world, "workload": "DDPM full T=120 ancestral sampling, 128x128x3, self-attention at the "
                                                                       "16x16 stage (C=128, 256 tokens, 8 heads), 128 images/GPU"}
+    del smp, m
+    torch.cuda.empty_cache()
+    # -- latent diffusion on 256x256x3 images: frozen Encoder (1/4 resolution, 32 latent channels), the same UNet denoiser on the
+    #    64x64x32 latents, Decoder after sampling.  A training step = encode the image batch + one denoiser step on the latents.
+    from dm_amd.neural_nets.autoencoders import Decoder, Encoder
+    torch.manual_seed(42 + int(os.environ.get("RANK", 0)))
+    enc = Encoder(3, (32, 32), 32, 2, drop_p=0.0, activation="gelu").to(dev)
+    dec = Decoder(3, 32, (32,), 2, drop_p=0.0, activation="gelu").to(dev)
+    m = dm_ddpm.LatentDDPM(dm_unets.BaseUNet, enc, dec, **YAML, is_conditional=False, img_channels=32, reconstruction_method="mse",
+                           latent_dim=512, device=dev).to(dev)
+    m.train()
+    b = 32
+    images = torch.rand(b, 3, 256, 256, device=dev) * 2 - 1
+    lat = torch.tanh(m.encode(images)).contiguous()
+    opt = FusedAdam([q for q in m.parameters() if q.requires_grad], lr=1e-3)
+    red = reducer_factory(m) if dist else None
+    step = graphs.PipelinedTrainStep(m, ELBOLoss("mse"), opt, lat, red, use_graph=use_graph)
+
+    def ldm_step():
+        lat.copy_(torch.tanh(m.encode(images)))
+        step.replay()
+
+    dt = timed(ldm_step, 10, 3, barrier, dist, dev)
+    out["train_ldm_256x256x3"] = {"value": b * world * 10 / dt, "unit": "images/s", "ms_per_step": 100 * dt, "batch_per_gpu": b, "n_gpus": world,
+                                  "workload": "latent diffusion train step on 256x256x3 images: frozen Encoder (eager, 32 latent channels at "
+                                              "64x64) + denoiser step on the latents, batch 32/GPU"}
+    m.eval()
+    smp = graphs.GraphedSampler(m, 32, (64, 64), use_graph=use_graph)
+    dt = timed(lambda: m.decode(smp.sample()), 1, 1, barrier, dist, dev)
+    out["sample_ldm_256x256x3"] = {"value": 32 * world / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / 120, "batch_per_gpu": 32, "n_gpus": world,
+                                   "workload": "latent diffusion sampling of 256x256x3 images: T=120 chain on 64x64x32 latents + Decoder, "
+                                               "32 images/GPU"}
     return out
 
 

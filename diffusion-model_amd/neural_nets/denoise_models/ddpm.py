@@ -185,3 +185,34 @@ class DDPM(nn.Module):
         """The byte image of a sampled tensor: (x + 1) / 2 clamped to [0, 1] (ddpm.py:163-165, utils/other_utils.py:14-37
         there), then torchvision's to_pil_image arithmetic, `pic.mul(255).byte()`: a truncation, not a rounding."""
         return ((x + 1) / 2).clamp_(0.0, 1.0).mul(255).to(torch.uint8)
+
+
+class LatentDDPM(DDPM):
+    """DDPM on autoencoder latents: the latent-diffusion configuration.  The reference only holds an unexecuted text of this
+    class (ddpm.py:203-387 there: a triple-quoted string), whose intent is kept: the denoiser's "image" is the latent tensor
+    (img_channels = latent channels), training data are encoder(images) with the autoencoder frozen and in eval mode, and
+    samples are decoder(sampled latents).  Every part (denoiser, schedule, reverse step, Encoder, Decoder) is pinned on its
+    own; no reference behaviour exists for the composition."""
+
+    def __init__(self, denoise_model: Type[nn.Module], encoder: nn.Module, decoder: nn.Module, T: int, beta: float = 0.25, **kwargs) -> None:
+        super().__init__(denoise_model, T, beta, **kwargs)
+        self.encoder, self.decoder = encoder, decoder
+        self.latent_channels = kwargs["img_channels"]
+        for p in list(encoder.parameters()) + list(decoder.parameters()):
+            p.requires_grad_(False)               # second-stage training moves the denoiser only
+
+    @torch.no_grad()
+    def encode(self, images: Tensor) -> Tensor:
+        """images (N,C,H,W) -> latents (N, latent_channels, h, w), the x_0 of q() and of the training step"""
+        self.encoder.eval()
+        return self.encoder(images)
+
+    @torch.no_grad()
+    def decode(self, latents: Tensor) -> Tensor:
+        self.decoder.eval()
+        return self.decoder(latents)
+
+    @torch.no_grad()
+    def sample_images(self, N: int, latent_shape: Union[int, Tuple[int, int]]) -> Tensor:
+        """the full T-step chain in latent space, then the decoder: (N, C, H, W) fp32 images"""
+        return self.decode(self.sample_tensor(N, latent_shape))

@@ -501,23 +501,24 @@ class UNetEngine:
             return out
 
         def head_unit(name: str, x0: Var, act: int = 0) -> Var:
-            """conv -> [tanh] -> NCHW fp32: a network's image head (at most 16 output channels)"""
+            """conv -> [tanh] -> NCHW fp32: a network's image head"""
             kind = sp.convs[name]
             bias = P.get(name + ".bias")
             cout = conv_dims(kind, P[name + ".weight"])[0]
-            if cout > 16 or act not in (0, hip.ACT["tanh"]):
-                raise ValueError("head_unit: at most 16 output channels, activation none or tanh")
+            if act not in (0, hip.ACT["tanh"]):
+                raise ValueError("head_unit: activation none or tanh")
+            cpad = (cout + 15) // 16 * 16
             y = ops.conv_forward(kind, x0.v, wc.fwd[name], bias, cout, act=act, f32_nchw=True)
             out = Var(y)
             if tape is not None:
                 def bwd():
                     n_, _, oh, ow = y.shape
-                    dz = torch.empty(n_, oh, ow, 16, device=dev, dtype=BF16)
+                    dz = torch.empty(n_, oh, ow, cpad, device=dev, dtype=BF16)
                     dy = out.g.contiguous()
                     if act:
-                        hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(y), hip.ptr(dz), n_, cout, oh * ow, 16, hip.stream())
+                        hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(y), hip.ptr(dz), n_, cout, oh * ow, cpad, hip.stream())
                     else:
-                        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(dy), hip.ptr(dz), n_, cout, oh * ow, 16, hip.stream())
+                        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(dy), hip.ptr(dz), n_, cout, oh * ow, cpad, hip.stream())
                     if bias is not None:
                         ops.colsum(dz, G[name + ".bias"], cout)
                     wgrad(kind, x0.v, dz, cout, name)
@@ -791,8 +792,9 @@ class UNetEngine:
         conv_unit, sir, embed, wgrad, part_alloc, part_entries, tap, finish = (c_.conv_unit, c_.sir, c_.embed, c_.wgrad, c_.part_alloc,
                                                                                c_.part_entries, c_.tap, c_.finish)
         # ---- the network ------------------------------------------------------------------------
-        xin = torch.empty(n, h, w, 16, device=dev, dtype=BF16)
-        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(xin), n, c_img, h * w, 16, hip.stream())
+        cpad = (c_img + 15) // 16 * 16                 # the image (or latent) channels padded to the convolution kernels' input granule
+        xin = torch.empty(n, h, w, cpad, device=dev, dtype=BF16)
+        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(xin), n, c_img, h * w, cpad, hip.stream())
         sin = torch.empty(n, 1, 1, sp.t_dim, device=dev, dtype=BF16)
         hip.call("ddpm_time_embedding", hip.ptr(t), sp.time_norm, sp.t_dim, hip.ptr(sin), n, hip.stream())
         sin_v = Var(sin, need_grad=False)
@@ -885,9 +887,9 @@ class UNetEngine:
             out_holder = Var(out)
 
             def bwd_head():
-                dz = torch.empty(n, h, w, 16, device=dev, dtype=BF16)
+                dz = torch.empty(n, h, w, cpad, device=dev, dtype=BF16)
                 dy = out_holder.g.contiguous()
-                hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, 16, hip.stream())
+                hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, cpad, hip.stream())
                 ops.colsum(dz, G[name + ".bias"], c_img)
                 wgrad(K33, hfeat.v, dz, c_img, name)
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3], c0_used=c_img if c_img <= 4 else 0)
