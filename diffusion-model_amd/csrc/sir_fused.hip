@@ -222,9 +222,13 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
                 for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
             }
         }
+        SIR_STAMP(10);
         if constexpr (IPW == 1) group_store<E, M>(s, ss, wave, v1, lane, s_part);
+        SIR_STAMP(11);
         __syncthreads();
+        SIR_STAMP(12);
         group_finish<E, M, HW, IPW>(tid, s_part, s_mr, a.eps, st_out, n0, a.N);
+        SIR_STAMP(13);
         __syncthreads();
     };
     // normalise + activation + dropout of xr[] -> LDS tile (in place) and optionally global memory

@@ -452,10 +452,11 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
 
 
 // GroupNorm (+activation, +dropout) backward for a tile too large to keep an fp32 copy of the gradient in registers:
-// both passes read the incoming gradient from the LDS tile (bf16) and the raw tensor from global memory (the second
-// time an L2 hit) and evaluate the activation derivative again, like the unfused two-pass kernel; the result
-// replaces the incoming gradient in the tile (every thread owns its elements) and optionally goes to global memory.
-// Same slot protocol as norm_bwd.
+// the first pass reads the incoming gradient from the LDS tile (bf16) and the raw tensor from global memory, evaluates
+// the activation derivative and puts g = dy * mask * act'(z) back into the tile (bf16, every thread owns its elements);
+// the second pass reads g from the tile and the raw tensor again (an L2 hit), so the derivative - most of the
+// instructions of this VALU-bound phase - is evaluated once.  The result replaces g in the tile and optionally goes to
+// global memory.  Same slot protocol as norm_bwd.
 template <int CH, int M, int HW, int CS, int ACT>
 __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* raw_g, const unsigned char* mask_g, long long elem0, float mscale,
                                               const float* gamma, const float* beta, const float* s_mr, float* s_slot, float* s_grp,
@@ -494,6 +495,23 @@ __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* ra
                 gg[k][j] = v;
             }
     };
+    // second pass: g comes back from the tile, only xhat is recomputed
+    auto chunk2 = [&](int k0, float (&gg)[4][8], float (&xh)[4][8]) {
+        bf16x8 raw[4], gin[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 * T::NV + k0 + k;
+            raw[k] = *(const bf16x8*)(raw_g + (long long)row * CH + vec * 8);
+            gin[k] = *(const bf16x8*)(tile + row * TS + vec * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xh[k][j] = ((float)raw[k][j] - mean[j]) * rstd[j];
+                gg[k][j] = (float)gin[k][j];
+            }
+    };
     float a1[8], a2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
@@ -502,9 +520,16 @@ __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* ra
         float gg[4][8], xh[4][8];
         chunk(k0, gg, xh);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
+            bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { a1[j] += gg[k][j]; a2[j] += gg[k][j] * xh[k][j]; }
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (bf16)gg[k][j];
+                const float gr = (float)o[j];            // the sums see the value the second pass will see
+                a1[j] += gr; a2[j] += gr * xh[k][j];
+            }
+            *(bf16x8*)(tile + (r0 * T::NV + k0 + k) * TS + vec * 16) = o;
+        }
     }
     col_store<CH, M, CS>(a1, wave, vec, lane, s_slot);
     col_store<CH, M, CS>(a2, wave, vec, lane, s_slot + NWV * CS);
@@ -534,7 +559,7 @@ __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* ra
 #pragma unroll 1
     for (int k0 = 0; k0 < T::NV; k0 += 4) {
         float gg[4][8], xh[4][8];
-        chunk(k0, gg, xh);
+        chunk2(k0, gg, xh);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = r0 * T::NV + k0 + k;
@@ -586,6 +611,7 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
     const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
     const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
     __syncthreads();
+    SIRB_STAMP(0);
 
     // ---- last GroupNorm backward: dy -> d_o (LDS [M][C] view + global)
     {
@@ -615,6 +641,7 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
     }
     __syncthreads();
     col2_flush<C, 1, E>(s_col, a.part3, n0, a.N, tid);
+    SIRB_STAMP(1);
 
     // ---- projection data-gradient: results wait in accumulators until every wave has read d_o, then fill the [M][E] tile
     {
@@ -651,11 +678,13 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
                 }
     }
     __syncthreads();
+    SIRB_STAMP(2);
 
     // ---- second GroupNorm + activation + dropout backward -> dd (in place in the tile)
     norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_d + row0 * E, use_mask ? a.m_d : nullptr, row0 * E, a.mscale, s_p + P_G2, s_p + P_B2,
                                     s_mr + 2 * SIR_G, s_col, s_grp, a.part2, nullptr, n0, tid);
     __syncthreads();
+    SIRB_STAMP(3);
     float* dwp = a.dwpart + n0 * 10 * E;
     for (int c = tid; c < E; c += SIR_THREADS) dwp[9 * E + c] = col_total<1, E>(s_col + 2 * NWV * E, 0, c);
 
@@ -713,6 +742,7 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
 #pragma unroll
         for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(dea[k0 + k]));    // convert now: the fp32 accumulators of a finished chunk are dead
     }
+    SIRB_STAMP(4);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) *(bf16x8*)(s_e + (r1 * E1::NV + k) * ES + v1 * 16) = dea[k];
@@ -727,11 +757,13 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
         __syncthreads();
     }
 
+    SIRB_STAMP(5);
     // ---- first GroupNorm + activation + dropout backward -> d_e (tile + global); own elements only, no barrier needed before
     norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_e + row0 * E, use_mask ? a.m_e : nullptr, row0 * E, a.mscale, s_p + P_G1, s_p + P_B1, s_mr,
                                     s_col, s_grp, a.part1, a.d_e + row0 * E, n0, tid);
     __syncthreads();
     col2_flush<E, 1, E>(s_col, a.part1, n0, a.N, tid);
+    SIRB_STAMP(6);
 
     // ---- expansion data-gradient (accumulators across a barrier, then the [M][C] view of the tile)
     {
@@ -760,6 +792,7 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
             }
     }
     __syncthreads();
+    SIRB_STAMP(7);
 
     // ---- dropout of the block input and the residual branch
 #pragma unroll
@@ -778,6 +811,7 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
         }
         *(bf16x8*)(a.dx + e) = o;
     }
+    SIRB_STAMP(8);
 }
 
 template <int C, int W>

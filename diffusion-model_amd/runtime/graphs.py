@@ -155,7 +155,6 @@ class PipelinedTrainStep:
         self.eng.phases = int(phases)
         self.eng.external_zero = self.accum > 1     # the driver clears the gradient sums (every k-th replay), not the backward pass
         import os
-        self.tail_on_main = os.environ.get("DDPM_TAIL_ON_MAIN", "0") == "1"
         self.eng.wgrad_tiles_last = int(os.environ.get("DDPM_TPS_LAST", self.eng.wgrad_tiles_last))
         self.eng.wgrad_tiles_per_split = int(os.environ.get("DDPM_TPS", self.eng.wgrad_tiles_per_split))
         self.K, self.mid = self.eng.phase_layout()      # mid: the phase after which the decoder half of the gradients is final
@@ -306,18 +305,6 @@ class PipelinedTrainStep:
                 if exchange:
                     self._exchange(p)
                 continue
-            if self.tail_on_main and p == self.K - 1 and not self._sep_adam:
-                # the last phase's leaf work (with the optimizer step at its end) follows on the main stream, which has
-                # nothing else to do: the next step's first graph then starts behind it on the same stream, instead of
-                # behind a cross-stream wait
-                main.wait_stream(self.side)
-                gw[p].replay()
-                self.ev_done.record(main)
-                if gp:
-                    self.side.wait_event(self.ev_done)
-                    with torch.cuda.stream(self.side):
-                        self._pre()
-                return
             self.events[p].record(main)
             self.side.wait_event(self.events[p])
             with torch.cuda.stream(self.side):

@@ -9,7 +9,7 @@ hip.LIB_PATH = os.path.join(ROOT, "tools/micro/libsirdbg.so")
 hip._lib = None
 lib = hip.lib()
 lib.ddpm_sir_set_dbg.argtypes = [ctypes.c_void_p]
-dev = torch.device("cuda:0"); BF = torch.bfloat16; N = 256
+dev = torch.device("cuda:0"); BF = torch.bfloat16; N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 names = ["prefetch+X->LDS", "expand GEMM", "read tile", "stats1", "apply1", "depthwise", "stats2", "apply2", "project GEMM", "GN3+res"]
 for (c, w) in [(32, 16), (64, 8), (128, 4), (256, 2)]:
     e = 2 * c
@@ -32,3 +32,9 @@ for (c, w) in [(32, 16), (64, 8), (128, 4), (256, 2)]:
         span = d[:, 9].max().item() - d[:, 0].min().item()
         print(f"C{c} {w}x{w} rec={rec}: waves {len(d)}; wave lifetime {tot:.0f} ticks; first start -> last end {span:.0f} ticks")
         print("   " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names[:9], ph.tolist())))
+        f = dbg.view(-1, 16).cpu()
+        f = f[f[:, 0] > 0].double()
+        if (f[:, 13] > 0).all():           # finer stamps of the second statistics phase (the last call overwrites the first)
+            base = f[:, 5]
+            print("   stats2 detail: accumulate %.0f  shuffle+store %.0f  barrier %.0f  finish %.0f  barrier %.0f" % tuple(
+                (f[:, i] - f[:, j]).mean().item() for i, j in ((10, 5), (11, 10), (12, 11), (13, 12), (6, 13))))

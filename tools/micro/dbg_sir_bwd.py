@@ -12,7 +12,8 @@ lib = hip.lib()
 lib.ddpm_sir_bwd_set_dbg.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0"); BF = torch.bfloat16; N = 256
 names = ["loads+tables", "GN3 bwd", "proj dgrad GEMM", "GN2 bwd", "depthwise", "GN1 bwd+store", "expand dgrad GEMM", "dx store"]
-for (c, w) in [(32, 16), (64, 8), (128, 4), (256, 2)]:
+names_big = ["GN3 bwd", "proj dgrad GEMM", "GN2 bwd", "depthwise", "tap sums", "GN1 bwd+store", "expand dgrad GEMM", "dx store"]
+for (c, w) in [(32, 32), (32, 16), (64, 8), (128, 4), (256, 2)]:
     e = 2 * c
     x = torch.randn(N, w, w, c, device=dev).to(BF)
     f = lambda *s: torch.randn(*s, device=dev) * 0.1
@@ -42,4 +43,4 @@ for (c, w) in [(32, 16), (64, 8), (128, 4), (256, 2)]:
     tot = (d[:, 8] - d[:, 0]).mean().item()
     span = d[:, 8].max().item() - d[:, 0][d[:, 0] > d[:, 0].median() - 1e7].min().item()
     print(f"C{c} {w}x{w}: waves {len(d)}; wave lifetime {tot:.0f} ticks; first start -> last end {span:.0f} ticks; kernel {us:.1f} us (with allocs/launch)")
-    print("   " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, ph.tolist())))
+    print("   " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names_big if w == 32 else names, ph.tolist())))
