@@ -392,6 +392,81 @@ extern "C" int ddpm_sample_timesteps(int64_t* t, int N, int T, const uint64_t* s
     return ddpm_check_launch("sample_timesteps");
 }
 
+// ------------------------------------------------------------------------------------------------
+// The head of a training step in one launch: per-image timestep draw (as sample_timesteps_kernel), forward noising
+// (as q_sample_kernel) written straight into the channel-padded NHWC bf16 tensor the stem convolution reads, the
+// sinusoidal time embedding (as time_embedding_kernel), and the seed advance (as bump_seed_kernel) by the last workgroup
+// to finish.  Five dependent tiny launches otherwise open every step on an idle queue.  Same draws, same arithmetic and
+// the same rounding points as the separate kernels.
+__device__ __forceinline__ long long draw_timestep(unsigned long long sd, int n, int T) {
+    const Philox4 r = philox4x32_10((uint32_t)(n >> 2), 0u, 3u, 0x3c6ef372u, (uint32_t)sd, (uint32_t)(sd >> 32));
+    const uint32_t w = (n & 3) == 0 ? r.x : (n & 3) == 1 ? r.y : (n & 3) == 2 ? r.z : r.w;
+    return 1 + (long long)(((unsigned long long)w * (unsigned)T) >> 32);
+}
+
+__global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict__ x0, const long long* __restrict__ t_in,
+                                                          const float* __restrict__ noise, const float* __restrict__ sched,
+                                                          long long* __restrict__ t_out, bf16* __restrict__ xt_nhwc, int cpad,
+                                                          bf16* __restrict__ sin_out, float inv_norm, int dim, int N, int C, int HW, int T,
+                                                          unsigned long long* __restrict__ seed, unsigned* __restrict__ done) {
+    const unsigned long long sd = *seed;
+    const long long chw = (long long)C * HW;
+    const long long total4 = (long long)N * chw / 4;
+    const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
+    for (long long q = gid; q < total4; q += gstride) {
+        const long long e = q * 4;
+        const int n = (int)(e / chw);
+        const int ti = (int)(t_in ? t_in[n] : draw_timestep(sd, n, T));
+        const float a = sched[ti * SC_STRIDE + SC_SQRT_AB], b = sched[ti * SC_STRIDE + SC_SQRT_1MAB];
+        const f32x4 x = *(const f32x4*)(x0 + e);
+        const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, 1u, (unsigned long long)q);
+        const long long r = e - (long long)n * chw;
+        const int c = (int)(r / HW);
+        const int p = (int)(r - (long long)c * HW);          // HW % 4 == 0: the four elements share n and c
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float o = a * x[j] + b * z[j];             // two roundings + one, as q_sample_kernel (no FMA)
+            bf16* px = xt_nhwc + ((long long)n * HW + p + j) * cpad;
+            px[c] = (bf16)o;
+            if (c == 0)
+                for (int cc = C; cc < cpad; ++cc) px[cc] = (bf16)0.f;
+        }
+    }
+    const int half = dim / 2;
+    for (long long i = gid; i < (long long)N * half; i += gstride) {
+        const int n = (int)(i / half), k = (int)(i - (long long)n * half);
+        const long long tn = t_in ? t_in[n] : draw_timestep(sd, n, T);
+        if (k == 0) t_out[n] = tn;
+        const float pre = 9.210340371976184f / (float)(half - 1);
+        const float f = expf(-pre * (float)k);
+        const float ang = ((float)tn * inv_norm) * f;
+        sin_out[n * dim + k] = (bf16)sinf(ang);
+        sin_out[n * dim + half + k] = (bf16)cosf(ang);
+    }
+    // the seed advances once every workgroup has read it: the last one to arrive here does it
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(done, 1u) == gridDim.x - 1) {
+            *seed = sd + 0x9E3779B97F4A7C15ull;
+            *done = 0u;
+        }
+    }
+}
+
+extern "C" int ddpm_train_head(const float* x0, const int64_t* t_in, const float* noise, const float* sched, int64_t* t_out, void* xt_nhwc,
+                               int cpad, void* sin_out, float time_norm, int t_dim, int N, int C, int HW, int T, uint64_t* seed,
+                               uint32_t* done, ddpm_stream_t stream_) {
+    DDPM_REQUIRE(x0 && sched && t_out && xt_nhwc && sin_out && seed && done, "train_head: null pointer");
+    DDPM_REQUIRE(N > 0 && C > 0 && HW > 0 && HW % 4 == 0 && cpad >= C && T > 0, "train_head: H*W must be a positive multiple of 4, cpad >= C");
+    DDPM_REQUIRE(t_dim >= 4 && t_dim % 2 == 0, "train_head: bad embedding width %d", t_dim);
+    const long long total4 = (long long)N * C * HW / 4;
+    hipLaunchKernelGGL(train_head_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream_, x0, (const long long*)t_in, noise,
+                       sched, (long long*)t_out, (bf16*)xt_nhwc, cpad, (bf16*)sin_out, 1.0f / time_norm, t_dim, N, C, HW, T,
+                       (unsigned long long*)seed, (unsigned*)done);
+    return ddpm_check_launch("train_head");
+}
+
 __global__ void bump_seed_kernel(unsigned long long* seed) { *seed += 0x9E3779B97F4A7C15ull; }
 
 extern "C" int ddpm_bump_seed(uint64_t* seed_, ddpm_stream_t stream_) {

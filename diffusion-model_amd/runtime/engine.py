@@ -774,15 +774,24 @@ class UNetEngine:
                                finish=flush, mscale=mscale)
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, params: Dict[str, Tensor], x: Tensor, t: Tensor, train: bool, record: bool,
-                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None, mask_ahead: bool = False):
+    def forward(self, params: Dict[str, Tensor], x: Optional[Tensor], t: Tensor, train: bool, record: bool,
+                masks: Optional[List[Tensor]] = None, taps: Optional[Dict[str, Tensor]] = None, mask_ahead: bool = False,
+                head: Optional[Tuple[Tensor, Tensor]] = None):
         """x: NCHW fp32 on the GPU, t: int64 [N].  Returns (out NCHW fp32, tape or None).
-        train enables dropout; record keeps what backward needs; mask_ahead: see _make_masks."""
+        train enables dropout; record keeps what backward needs; mask_ahead: see _make_masks.
+        head = (stem input as channel-padded NHWC bf16 [N,H,W,cpad], sinusoidal embedding bf16 [N,1,1,t_dim]) when a caller has
+        produced both already (ddpm_train_head): x is then not read."""
         sp = self.spec
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == sp.img_channels
-        x = x.contiguous()
         t = t.to(torch.long).contiguous()
-        n, c_img, h, w = x.shape
+        if head is not None:
+            n, h, w = head[0].shape[:3]
+            c_img = sp.img_channels
+            assert head[0].shape[3] == (c_img + 15) // 16 * 16 and head[0].dtype == BF16 and head[1].numel() == n * sp.t_dim
+            x = head[0]
+        else:
+            assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == sp.img_channels
+            x = x.contiguous()
+            n, c_img, h, w = x.shape
         nst = len(sp.stages)
         if h % (1 << nst) or w % (1 << nst):
             raise ValueError(f"image size {h}x{w} must be divisible by {1 << nst}")
@@ -793,10 +802,13 @@ class UNetEngine:
                                                                                c_.part_entries, c_.tap, c_.finish)
         # ---- the network ------------------------------------------------------------------------
         cpad = (c_img + 15) // 16 * 16                 # the image (or latent) channels padded to the convolution kernels' input granule
-        xin = torch.empty(n, h, w, cpad, device=dev, dtype=BF16)
-        hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(xin), n, c_img, h * w, cpad, hip.stream())
-        sin = torch.empty(n, 1, 1, sp.t_dim, device=dev, dtype=BF16)
-        hip.call("ddpm_time_embedding", hip.ptr(t), sp.time_norm, sp.t_dim, hip.ptr(sin), n, hip.stream())
+        if head is not None:
+            xin, sin = head[0], head[1].view(n, 1, 1, sp.t_dim)
+        else:
+            xin = torch.empty(n, h, w, cpad, device=dev, dtype=BF16)
+            hip.call("ddpm_nchw_f32_to_nhwc_bf16", hip.ptr(x), hip.ptr(xin), n, c_img, h * w, cpad, hip.stream())
+            sin = torch.empty(n, 1, 1, sp.t_dim, device=dev, dtype=BF16)
+            hip.call("ddpm_time_embedding", hip.ptr(t), sp.time_norm, sp.t_dim, hip.ptr(sin), n, hip.stream())
         sin_v = Var(sin, need_grad=False)
 
         e, d = "encoder.", "decoder."

@@ -159,6 +159,7 @@ class PipelinedTrainStep:
         self.eng.wgrad_tiles_per_split = int(os.environ.get("DDPM_TPS", self.eng.wgrad_tiles_per_split))
         self.K, self.mid = self.eng.phase_layout()      # mid: the phase after which the decoder half of the gradients is final
         self.loss = torch.zeros(1, device=x0.device)
+        self._head_done = torch.zeros(1, device=x0.device, dtype=torch.int32)      # ddpm_train_head's last-workgroup counter
         self._ctx = None
         self._ranges = [None, None]
         self._ready = [False] * self.K
@@ -206,10 +207,21 @@ class PipelinedTrainStep:
             return
         from . import hip
         core, n = self.core, self.x0.shape[0]
-        t = self.t_in if self.t_in is not None else core.sample_timesteps(n, self.x0.device)
-        x_t = core.q(self.x0, t, noise=self.noise_in)
         params = dict(zip(self.unet._param_names, self.unet.parameters()))
-        pred, self._ctx = self.eng.forward(params, x_t, t, train=self.unet.training, record=True, mask_ahead=True)
+        # timestep draw, forward noising (straight into the stem convolution's input layout), time embedding and seed advance
+        # in one launch: the same numbers as core.sample_timesteps + core.q + the engine's own layout bridge and embedding
+        _, c, h, w = self.x0.shape
+        dev = self.x0.device
+        sp = self.eng.spec
+        cpad = (c + 15) // 16 * 16
+        t = torch.empty(n, device=dev, dtype=torch.long)
+        xin = torch.empty(n, h, w, cpad, device=dev, dtype=torch.bfloat16)
+        sin = torch.empty(n, sp.t_dim, device=dev, dtype=torch.bfloat16)
+        x0 = self.x0 if self.x0.dtype == torch.float32 and self.x0.is_contiguous() else self.x0.float().contiguous()
+        hip.call("ddpm_train_head", hip.ptr(x0), hip.ptr(self.t_in), hip.ptr(self.noise_in), hip.ptr(core.schedule_table(dev)), hip.ptr(t),
+                 hip.ptr(xin), cpad, hip.ptr(sin), sp.time_norm, sp.t_dim, n, c, h * w, core.T, hip.ptr(core._rng_seed(dev)),
+                 hip.ptr(self._head_done), hip.stream())
+        pred, self._ctx = self.eng.forward(params, None, t, train=self.unet.training, record=True, mask_ahead=True, head=(xin, sin))
         table = self.criterion._table(core, pred.device)
         chw = pred.numel() // n
         flags = (int(self.criterion.bce), int(bool(self.criterion.use_elbo)))

@@ -110,6 +110,7 @@ _PROTOS = {
     "ddpm_abi_version": ([], _i),
     "ddpm_q_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _u32, _vp], _i),
     "ddpm_reverse_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _u32, _i, C.c_uint64, _vp], _i),
+    "ddpm_train_head": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "ddpm_fill_normal": ([_vp, _i64, _vp, _u32, C.c_uint64, _vp], _i),
     "ddpm_elbo_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
     "ddpm_elbo_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),

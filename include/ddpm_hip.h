@@ -53,6 +53,15 @@ int ddpm_abi_version(void);
 int ddpm_q_sample(const float* x0, const int64_t* t, const float* noise, const float* sched, float* xt, void* xt_nhwc,
                   int cpad, int N, int C, int HW, const uint64_t* seed, uint32_t stream_id, ddpm_stream_t stream);
 
+/* The head of a training micro-step in one launch (base_trainer.py:202-204: torch.randint(1, T + 1, (N,)), DDPM.q; unets.py:121:
+ * the sinusoidal embedding of t / time_norm): t_out[n] = the timestep of image n (t_in when given, else drawn as
+ * ddpm_sample_timesteps with stream 3 does), x_t = q(x0, t) with in-kernel noise of stream 1 (or `noise`) written as the
+ * channel-padded NHWC bf16 tensor the stem convolution reads (padding zeroed), sin_out = bf16 [N][t_dim] as
+ * ddpm_time_embedding, and *seed advanced as ddpm_bump_seed does.  `done`: one zero-initialised uint32 of device memory the
+ * launch uses to find its last workgroup (left at zero).  Same numbers as the separate calls. */
+int ddpm_train_head(const float* x0, const int64_t* t_in, const float* noise, const float* sched, int64_t* t_out, void* xt_nhwc,
+                    int cpad, void* sin_out, float time_norm, int t_dim, int N, int C, int HW, int T, uint64_t* seed, uint32_t* done,
+                    ddpm_stream_t stream);
 /* DDPM.reverse_q (ddpm.py:113-144): out = A_t x_t + B_t x0_pred + C_t z.  sigmoid_pred applies the "bce" branch
  * of DDPM.sample (ddpm.py:158-159) to x0_pred first.  z drawn in-kernel (noise == NULL) is the Philox sample of GLOBAL flat
  * element first_index + i (a multiple of 4): a rank that holds images [b, e) of a sharded sampling job passes

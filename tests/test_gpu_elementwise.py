@@ -136,3 +136,41 @@ def test_timesteps_match_the_philox_oracle_bit_for_bit(dev):
     assert not torch.equal(a, b)
     counts = torch.bincount(a.cpu(), minlength=121)[1:].float()
     assert counts.min() > 10 and counts.max() < 70          # 4096 / 120 = 34 expected per value
+
+
+@pytest.mark.parametrize("n,c,h", [(5, 1, 8), (3, 3, 4), (2, 32, 4), (256, 1, 32)])
+def test_train_head_equals_the_separate_kernels(dev, n, c, h):
+    """ddpm_train_head (timestep draw + forward noising into the stem layout + time embedding + seed advance in one launch)
+    against the entry points it stands for, bit for bit: ddpm_sample_timesteps (stream 3), ddpm_q_sample (stream 1, NHWC bf16
+    output), ddpm_time_embedding and ddpm_bump_seed; with drawn and with injected timesteps / noise."""
+    T, dim, cpad = 120, 32, (c + 15) // 16 * 16
+    x0 = (hash_uniform((n, c, h, h), 3) * 2 - 1).to(dev)
+    tab = torch.rand(T + 1, 8, device=dev)
+    for inject in (False, True):
+        seed_a = torch.tensor([0x5EED_1234_5678], device=dev, dtype=torch.long)
+        seed_b = seed_a.clone()
+        t_in = torch.randint(1, T + 1, (n,), device=dev) if inject else None
+        z_in = hash_normal((n, c, h, h), 4).to(dev) if inject else None
+        # the separate kernels
+        t_ref = t_in if inject else torch.empty(n, device=dev, dtype=torch.long)
+        if not inject:
+            hip.call("ddpm_sample_timesteps", hip.ptr(t_ref), n, T, hip.ptr(seed_a), 3, hip.stream())
+        x_ref = torch.full((n, h, h, cpad), 7.0, device=dev, dtype=torch.bfloat16)
+        hip.call("ddpm_q_sample", hip.ptr(x0), hip.ptr(t_ref), hip.ptr(z_in), hip.ptr(tab), None, hip.ptr(x_ref), cpad, n, c, h * h,
+                 hip.ptr(seed_a), 1, hip.stream())
+        hip.call("ddpm_bump_seed", hip.ptr(seed_a), hip.stream())
+        s_ref = torch.empty(n, dim, device=dev, dtype=torch.bfloat16)
+        hip.call("ddpm_time_embedding", hip.ptr(t_ref), 100.0, dim, hip.ptr(s_ref), n, hip.stream())
+        # one launch
+        t_out = torch.empty(n, device=dev, dtype=torch.long)
+        x_out = torch.full((n, h, h, cpad), 7.0, device=dev, dtype=torch.bfloat16)
+        s_out = torch.empty(n, dim, device=dev, dtype=torch.bfloat16)
+        done = torch.zeros(1, device=dev, dtype=torch.int32)
+        for _ in range(2):                      # twice: the counter returns to zero, the seed advances once per call
+            seed_b.copy_(torch.tensor([0x5EED_1234_5678], device=dev))
+            hip.call("ddpm_train_head", hip.ptr(x0), hip.ptr(t_in), hip.ptr(z_in), hip.ptr(tab), hip.ptr(t_out), hip.ptr(x_out), cpad,
+                     hip.ptr(s_out), 100.0, dim, n, c, h * h, T, hip.ptr(seed_b), hip.ptr(done), hip.stream())
+        assert torch.equal(t_out, t_ref) and int(done) == 0
+        assert torch.equal(x_out, x_ref)
+        assert torch.equal(s_out, s_ref)
+        assert torch.equal(seed_a, seed_b)
