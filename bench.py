@@ -146,8 +146,8 @@ def extra_configs(dev, world, dist, barrier, reducer_factory, use_graph):
     x0 = torch.rand(b, 3, 64, 64, device=dev) * 2 - 1
     red = reducer_factory(m) if dist else None
     step = graphs.PipelinedTrainStep(m, ELBOLoss("mse"), opt, x0, red, use_graph=use_graph)
-    dt = timed(step.replay, 20, 5, barrier, dist, dev)
-    out["train_64x64x3"] = {"value": b * world * 20 / dt, "unit": "images/s", "ms_per_step": 50 * dt, "batch_per_gpu": b, "n_gpus": world,
+    dt = timed(step.replay, 40, 15, barrier, dist, dev)
+    out["train_64x64x3"] = {"value": b * world * 40 / dt, "unit": "images/s", "ms_per_step": 25 * dt, "batch_per_gpu": b, "n_gpus": world,
                             "workload": "DDPM train step, 64x64x3 (Flowers102-shaped), batch 128/GPU, drop_p=0.1, Adam"}
     m.eval()
     smp = graphs.GraphedSampler(m, 256, (64, 64), use_graph=use_graph)
@@ -187,8 +187,8 @@ def extra_configs(dev, world, dist, barrier, reducer_factory, use_graph):
         lat.copy_(torch.tanh(m.encode(images)))
         step.replay()
 
-    dt = timed(ldm_step, 10, 3, barrier, dist, dev)
-    out["train_ldm_256x256x3"] = {"value": b * world * 10 / dt, "unit": "images/s", "ms_per_step": 100 * dt, "batch_per_gpu": b, "n_gpus": world,
+    dt = timed(ldm_step, 20, 10, barrier, dist, dev)
+    out["train_ldm_256x256x3"] = {"value": b * world * 20 / dt, "unit": "images/s", "ms_per_step": 50 * dt, "batch_per_gpu": b, "n_gpus": world,
                                   "workload": "latent diffusion train step on 256x256x3 images: frozen Encoder (eager, 32 latent channels at "
                                               "64x64) + denoiser step on the latents, batch 32/GPU"}
     m.eval()

@@ -18,6 +18,25 @@ def _engines(ddpm):
     return [core.model._get_engine()]
 
 
+_STREAM_POOL: dict = {}
+
+
+def _pool_stream(device, k: int = 0) -> "torch.cuda.Stream":
+    """Stream k of a small per-device pool created once, in one go, for the life of the process: the side stream of the
+    pipelined drivers (k = 0) and the streams of concurrent sampling chains.  Streams are dealt onto a few hardware queues in
+    creation order, so a fresh stream per driver instance can land on the queue the main stream uses, and the two halves of
+    the pipeline then run one after the other (measured: 7.15 instead of 6.47 ms per 64x64x3 step for the second driver of a
+    process).  The first streams a process creates sit on queues of their own."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _STREAM_POOL:
+        _STREAM_POOL[key] = [torch.cuda.Stream(device=key) for _ in range(3)]
+    pool = _STREAM_POOL[key]
+    while k >= len(pool):
+        pool.append(torch.cuda.Stream(device=key))
+    return pool[k]
+
+
 class GraphedTrainStep:
     """randint t -> q -> UNet -> ELBO -> backward -> [grad hook, e.g. all-reduce] -> optimizer.step, as one graph.
 
@@ -166,7 +185,7 @@ class PipelinedTrainStep:
         self._bound = False
         self._handles = []
         self.graphs = None
-        self.side = torch.cuda.Stream()
+        self.side = _pool_stream(x0.device, 0)
         self.events = [torch.cuda.Event() for _ in range(self.K)]
         self.ev_done = torch.cuda.Event()
         s = torch.cuda.Stream()
@@ -374,7 +393,8 @@ class ConcurrentSampler:
     def __init__(self, ddpm, n: int, shape, streams: int = 2, *, use_graph: bool = True, first_image: int = 0,
                  seed: Optional[int] = None):
         self.ddpm = ddpm
-        self.streams = [torch.cuda.Stream() for _ in range(streams)]
+        dev = next(ddpm.parameters()).device
+        self.streams = [_pool_stream(dev, k) for k in range(streams)]
         self.samplers = []
         for k, s in enumerate(self.streams):
             s.wait_stream(torch.cuda.current_stream())
