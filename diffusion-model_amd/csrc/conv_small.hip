@@ -33,7 +33,10 @@ struct SmallConvArgs {
 
 // KS = MFMA k-steps per wave and tap (Cin = 64 * KS).  The weight fragments of a whole group of taps are requested at once
 // (all nine for KS <= 4, three at a time - double buffered - for KS = 8): one L2 round trip per group instead of one per tap.
-template <int W, int KS>
+// A: the activation of the fused GroupNorm (forward epilogue or backward loader) as a compile-time code for the hot ones
+// (gelu, silu, none), -1 = the runtime code: a runtime switch inside the unrolled element loops costs a scalar branch per
+// element and keeps the compiler from packing the arithmetic.
+template <int W, int KS, int A>
 __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) {
     constexpr int HW = W * W;
     constexpr int MB = HW > 32 ? HW / 32 : 1, ROWS = 32 * MB;     // 32-row MFMA blocks per tile: an 8x8 image is two
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[k][j] = ((float)xv[j] - mean[j]) * rstd[j];
-                    gv[k][j] = (float)dv[j] * act_bwd(xh[k][j] * ga[j] + be[j], a.gnb_act);
+                    gv[k][j] = (float)dv[j] * act_bwd(xh[k][j] * ga[j] + be[j], A >= 0 ? A : a.gnb_act);
                     a1[j] += gv[k][j]; a2[j] += gv[k][j] * xh[k][j];
                 }
             }
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float sc = gam[j] * rstd, sh = bet[j] - mean * sc;
-            float y = act_fwd(val[mb][j] * sc + sh, a.gn_act);
+            float y = act_fwd(val[mb][j] * sc + sh, A >= 0 ? A : a.gn_act);
             if (a.gn_res) y += (float)rv4[mb][j];
             o[j] = (bf16)y;
         }
@@ -403,15 +406,24 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     dim3 grid((unsigned)((rows + tile_rows - 1) / tile_rows), (unsigned)(d->CoutW / 32));
     const int ks = Cin / 64;
     if (ks != 1 && ks != 2 && ks != 4 && ks != 8) return 0;
-#define SMALL_CASE(Wv, KSv)                                                                                                      \
-    if (d->IW == Wv && ks == KSv) {                                                                                              \
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_small_kernel<Wv, KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    const int key = d->gnb_raw ? d->gnb_act : d->gn_gamma ? d->gn_act : ACT_NONE;      // the fused GroupNorm's activation
+#define SMALL_LAUNCH(Wv, KSv, Av)                                                                                                \
+    {                                                                                                                            \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_small_kernel<Wv, KSv, Av>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                    (int)lds) != hipSuccess)                                                      \
             return ddpm_check_launch("conv_small: raise dynamic LDS limit") ? -1 : -1;                                           \
-        hipLaunchKernelGGL((conv_small_kernel<Wv, KSv>), grid, dim3(256), lds, stream, a);                                        \
+        hipLaunchKernelGGL((conv_small_kernel<Wv, KSv, Av>), grid, dim3(256), lds, stream, a);                                    \
+    }
+#define SMALL_CASE(Wv, KSv)                                                                                                      \
+    if (d->IW == Wv && ks == KSv) {                                                                                              \
+        if (key == ACT_GELU) SMALL_LAUNCH(Wv, KSv, ACT_GELU)                                                                     \
+        else if (key == ACT_SILU) SMALL_LAUNCH(Wv, KSv, ACT_SILU)                                                                \
+        else if (key == ACT_NONE) SMALL_LAUNCH(Wv, KSv, ACT_NONE)                                                                \
+        else SMALL_LAUNCH(Wv, KSv, -1)                                                                                           \
     }
     SMALL_CASE(2, 1) SMALL_CASE(2, 2) SMALL_CASE(2, 4) SMALL_CASE(2, 8) SMALL_CASE(4, 1) SMALL_CASE(4, 2) SMALL_CASE(4, 4) SMALL_CASE(4, 8)
     SMALL_CASE(8, 1) SMALL_CASE(8, 2) SMALL_CASE(8, 4)
 #undef SMALL_CASE
+#undef SMALL_LAUNCH
     return ddpm_check_launch("conv_small") == DDPM_OK ? 1 : -1;
 }

@@ -325,6 +325,9 @@ extern "C" int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int 
 // stem, conv_block.py:19-54 there with norm = None): dx = dy * act'(x), plus the column sums of dx (the convolution's
 // bias gradient) as one partial row per workgroup: part[(n * P + p)][C], image n cut into P pixel ranges.  Many
 // workgroups per image: the tensors of these units are the largest of the network and the work is pure streaming.
+// A: the activation as a compile-time code (gelu, silu), -1 = the runtime code (a runtime switch per element is a scalar
+// branch per element and keeps the arithmetic from being packed).
+template <int A>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx,
                                                        float* __restrict__ part, int HW, int C, int P, int act) {
     __shared__ float s_red[4 * 64];
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ x
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float d = (float)dv[j] * act_bwd((float)xv[j], act);
+            const float d = (float)dv[j] * act_bwd((float)xv[j], A >= 0 ? A : act);
             sum[j] += d;
             o[j] = (bf16)d;
         }
@@ -364,8 +367,8 @@ extern "C" int ddpm_act_backward(const void* x, const void* dy, void* dx, float*
     DDPM_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "act_backward: C must be 8, 16, 32 or 64 (got %d)", C);
     DDPM_REQUIRE(P > 0 && HW % P == 0 && (long long)N * P < (1ll << 31), "act_backward: P (%d) must divide H*W (%d)", P, HW);
     DDPM_REQUIRE(act >= 0 && act <= ACT_LAST && !ACT_HAS_BETA(act), "act_backward: unknown activation %d (swish / hardswish go through ddpm_gn_act_backward)", act);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(N * P)), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, (bf16*)dx, part, HW,
-                       C, P, act);
+    auto k = act == ACT_GELU ? act_bwd_kernel<ACT_GELU> : act == ACT_SILU ? act_bwd_kernel<ACT_SILU> : act_bwd_kernel<-1>;
+    hipLaunchKernelGGL(k, dim3((unsigned)(N * P)), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, (bf16*)dx, part, HW, C, P, act);
     return ddpm_check_launch("act_backward");
 }
 

@@ -14,6 +14,19 @@
 
 #include <mutex>
 
+// Kernel bodies are compiled once per hot activation (A = gelu, silu, none: the activation folds to straight-line code) and
+// once with A = -1, where the runtime code selects (every other activation, swish / hardswish with their scalar included).
+// A runtime switch inside the unrolled element loops costs a scalar branch per element and keeps the compiler from packing
+// the arithmetic: the GroupNorm of a 128x128 image is a stream of a few hundred MB through exactly these loops.
+#define GN_ACT(A, a) ((A) >= 0 ? (A) : (a).act)
+#define GN_BY_ACT(BODY, ...)                                       \
+    do {                                                           \
+        if (a.act == ACT_GELU) BODY<__VA_ARGS__, ACT_GELU>(a);     \
+        else if (a.act == ACT_SILU) BODY<__VA_ARGS__, ACT_SILU>(a); \
+        else if (a.act == ACT_NONE) BODY<__VA_ARGS__, ACT_NONE>(a); \
+        else BODY<__VA_ARGS__, -1>(a);                             \
+    } while (0)
+
 struct GnArgs {
     const bf16* x;             // [N][HW][C] raw convolution output
     const float* gamma;        // [C]
@@ -43,8 +56,8 @@ struct GnArgs {
 // CU with a single workgroup, so the waves must come from the workgroup size (up to 512 threads = 8 waves; 1024
 // threads would cap the kernel at 128 VGPRs and spill).
 
-template <int THREADS, int NV>
-__global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
+template <int THREADS, int NV, int A>
+__device__ __forceinline__ void gn_fwd_body(const GnArgs& a) {
     __shared__ float s_red[(THREADS / 64) * 64 < 128 ? 128 : (THREADS / 64) * 64];
     __shared__ float s_mean[32], s_rstd[32];
     const int tid = threadIdx.x;
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
 
     constexpr bool CACHED = NV > 0;
     constexpr int GN_NV = NV > 0 ? NV : 1;
-    const float bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
+    const float bsc = (A < 0 && ACT_HAS_BETA(a.act)) ? *a.act_beta : 1.f;
     // per-channel affine parameters are fetched up front so their latency overlaps the slab loads
     float gam[8], bet[8];
 #pragma unroll
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     auto finish = [&](const bf16x8& v, long long e) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act, bsc);
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], GN_ACT(A, a), bsc);
         if (a.mask) {
             const unsigned m = a.mask[e >> 3];
 #pragma unroll
@@ -177,11 +190,14 @@ __global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) {
     }
 }
 
+template <int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void gn_fwd_kernel(const GnArgs a) { GN_BY_ACT(gn_fwd_body, THREADS, NV); }
+
 // Backward.  With g = dy * mask * act'(z), xhat = (x - mean) rstd, m = cpg*HW:
 //   dgamma_c = sum g xhat,  dbeta_c = sum g,
 //   dx = rstd * ( gamma_c g - (S1 + xhat S2)/m ),  S1 = sum_group gamma g,  S2 = sum_group gamma g xhat.
-template <int THREADS, int NV>
-__global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
+template <int THREADS, int NV, int A>
+__device__ __forceinline__ void gn_bwd_body(const GnArgs& a) {
     __shared__ float s_red[(THREADS / 64) * 64 < 128 ? 128 : (THREADS / 64) * 64];
     __shared__ float s_s1[32], s_s2[32];
     const int tid = threadIdx.x;
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
             ga[j] = 1.f; be[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f;
         }
     }
-    const bool hb = ACT_HAS_BETA(a.act);
+    const bool hb = A < 0 && ACT_HAS_BETA(a.act);
     const float bsc = hb ? *a.act_beta : 1.f;
     float ab[8];                                  // swish / hardswish: per-channel sums for the scalar's gradient
 #pragma unroll
@@ -218,9 +234,10 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
         for (int j = 0; j < 8; ++j) {
             xh[j] = ((float)xv[j] - mean[j]) * rstd[j];
             const float z = xh[j] * ga[j] + be[j];
-            const float gg = (float)dv[j] * act_bwd(z, a.act, bsc) * ms;
+            const float gg = (float)dv[j] * act_bwd(z, GN_ACT(A, a), bsc) * ms;
             g[j] = (m >> j) & 1 ? gg : 0.f;
-            if (hb && acc) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, bsc) * ms : 0.f;
+            if constexpr (A < 0)
+                if (hb && acc) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, bsc) * ms : 0.f;
         }
     };
     // cached path: x stays in registers as bf16, the activation-gradient term g as fp32 (so exp/erf run once)
@@ -346,6 +363,9 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) {
     }
 }
 
+template <int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) { GN_BY_ACT(gn_bwd_body, THREADS, NV); }
+
 // ---- split path for large images --------------------------------------------------------------------------------
 // One workgroup per (image, slab) walks a 64x64 or 128x128 image alone for hundreds of microseconds while most of the
 // machine idles.  For such slabs the pixels are cut into P splits: a first launch reduces every split to partial sums
@@ -391,7 +411,8 @@ __global__ __launch_bounds__(GS_T) void gn_fwd_split_stats_kernel(const GnArgs a
     }
 }
 
-__global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a) {
+template <int T_, int A>
+__device__ __forceinline__ void gn_fwd_split_apply_body(const GnArgs& a) {
     __shared__ float s_mean[32], s_rstd[32];
     const int tid = threadIdx.x;
     const int slabs = a.C / a.SC;
@@ -435,14 +456,14 @@ __global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a
         }
     }
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
-    const float bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
+    const float bsc = (A < 0 && ACT_HAS_BETA(a.act)) ? *a.act_beta : 1.f;
 #pragma unroll 2
     for (int r = r0 + prow; r < r1; r += pstep) {
         const long long e = base + (long long)r * a.C;
         const bf16x8 v = *(const bf16x8*)(a.x + e);
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], a.act, bsc);
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], GN_ACT(A, a), bsc);
         if (a.mask) {
             const unsigned m = a.mask[e >> 3];
 #pragma unroll
@@ -460,6 +481,8 @@ __global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a
     }
 }
 
+__global__ __launch_bounds__(GS_T) void gn_fwd_split_apply_kernel(const GnArgs a) { GN_BY_ACT(gn_fwd_split_apply_body, GS_T); }
+
 // g = dy * mask * act'(z) and xhat of one vector (shared by the two backward split kernels)
 struct GnBwdLane {
     float ga[8], be[8], mean[8], rstd[8];
@@ -467,7 +490,7 @@ struct GnBwdLane {
 };
 __device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, GnBwdLane& L) {
     const int cpg = a.G > 0 ? a.C / a.G : 1;
-    L.bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;
+    L.bsc = ACT_HAS_BETA(a.act) ? *a.act_beta : 1.f;       // (the specialised bodies never read it)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (a.G > 0) {
@@ -481,6 +504,7 @@ __device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, 
     }
 }
 // ab != nullptr: also adds this vector's terms of the activation scalar's gradient
+template <int A>
 __device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, long long e, float (&g)[8], float (&xh)[8], float (&xf)[8],
                                           float* ab = nullptr) {
     const bf16x8 xv = *(const bf16x8*)(a.x + e), dv = *(const bf16x8*)(a.dy + e);
@@ -491,9 +515,10 @@ __device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, l
         xf[j] = (float)xv[j];
         xh[j] = (xf[j] - L.mean[j]) * L.rstd[j];
         const float z = xh[j] * L.ga[j] + L.be[j];
-        const float gg = (float)dv[j] * act_bwd(z, a.act, L.bsc) * ms;
+        const float gg = (float)dv[j] * act_bwd(z, GN_ACT(A, a), L.bsc) * ms;
         g[j] = (m >> j) & 1 ? gg : 0.f;
-        if (ab) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
+        if constexpr (A < 0)
+            if (ab) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
     }
 }
 
@@ -501,7 +526,8 @@ __device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, l
 __device__ __host__ __forceinline__ int gn_bwd_rows(int act) { return ACT_HAS_BETA(act) ? 4 : 3; }
 
 // scratch layout (backward): [N][P][rows][C] per split and channel
-__global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a) {
+template <int T_, int A>
+__device__ __forceinline__ void gn_bwd_split_sums_body(const GnArgs& a) {
     __shared__ float s_red[(GS_T / 64) * 64 < 128 ? 128 : (GS_T / 64) * 64];
     const int tid = threadIdx.x;
     const int slabs = a.C / a.SC;
@@ -515,13 +541,13 @@ __global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a)
     float a1[8], a2[8], sx[8], ab[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a1[j] = a2[j] = sx[j] = ab[j] = 0.f;
-    const bool hb = ACT_HAS_BETA(a.act);
+    const bool hb = A < 0 && ACT_HAS_BETA(a.act);
     const int R = gn_bwd_rows(a.act);
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
 #pragma unroll 2
     for (int r = r0 + prow; r < r1; r += pstep) {
         float g[8], xh[8], xf[8];
-        gn_bwd_gx(a, L, base + (long long)r * a.C, g, xh, xf, hb ? ab : nullptr);
+        gn_bwd_gx<A>(a, L, base + (long long)r * a.C, g, xh, xf, hb ? ab : nullptr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
     }
@@ -540,7 +566,10 @@ __global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a)
     }
 }
 
-__global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a) {
+__global__ __launch_bounds__(GS_T) void gn_bwd_split_sums_kernel(const GnArgs a) { GN_BY_ACT(gn_bwd_split_sums_body, GS_T); }
+
+template <int T_, int A>
+__device__ __forceinline__ void gn_bwd_split_apply_body(const GnArgs& a) {
     __shared__ float s_a1[64], s_a2[64], s_sx[64], s_s1[32], s_s2[32];
     const int tid = threadIdx.x;
     const int slabs = a.C / a.SC;
@@ -602,13 +631,15 @@ __global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a
     for (int r = r0 + prow; r < r1; r += pstep) {
         const long long e = base + (long long)r * a.C;
         float g[8], xh[8], xf[8];
-        gn_bwd_gx(a, L, e, g, xh, xf);
+        gn_bwd_gx<A>(a, L, e, g, xh, xf);
         bf16x8 w;
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = (bf16)(L.rstd[j] * (L.ga[j] * g[j] - (S1[j] + xh[j] * S2[j])));
         *(bf16x8*)(a.y + e) = w;
     }
 }
+
+__global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a) { GN_BY_ACT(gn_bwd_split_apply_body, GS_T); }
 
 // splits of a slab's pixels on the split path (0 = the slab is small enough for one workgroup)
 static int gn_splits(const GnArgs& a) {
