@@ -265,10 +265,26 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
     for (int nt = 0; nt < NT; ++nt) {
         const int col = wave_n * BNW + nt * 32 + (lane & 31);
         const float b = bias_r[nt];
+        // the activation code is uniform: decide once per tile, not inside the unrolled element loop (a switch there is a
+        // scalar branch per element)
+        if (a.act == ACT_NONE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            *(bf16*)(s_out + row * OS + col * 2) = (bf16)act_fwd(acc[nt][r] + b, a.act);
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_out + row * OS + col * 2) = (bf16)(acc[nt][r] + b);
+            }
+        } else if (a.act == ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_out + row * OS + col * 2) = (bf16)act_fwd(acc[nt][r] + b, ACT_GELU);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                *(bf16*)(s_out + row * OS + col * 2) = (bf16)act_fwd(acc[nt][r] + b, a.act);
+            }
         }
     }
     __syncthreads();
@@ -302,8 +318,16 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
         }
         if (a.out2) {                  // Cout % 8 == 0 (host-checked)
             bf16x8 y;
+            if (a.act2 == ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)v[j], a.act2);
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)v[j], ACT_GELU);
+            } else if (a.act2 == ACT_SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)v[j], ACT_SILU);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)v[j], a.act2);
+            }
             *(bf16x8*)(a.out2 + e) = y;
         }
     }

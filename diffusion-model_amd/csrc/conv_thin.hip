@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int co = q * 8 + j;
-            o[j] = (bf16)act_fwd(acc[co] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
+            const float v = acc[co] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
+            o[j] = (bf16)(a.act == ACT_NONE ? v : act_fwd(v, a.act));      // the stem hands its activated result out as out2
         }
         *(bf16x8*)(s_out + tid * 80 + q * 16) = o;
     }
@@ -173,8 +174,16 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
             for (int j = 0; j < a.Cout - q * 8; ++j) a.out[e + j] = o[j];
         if (a.out2 && q * 8 + 8 <= a.Cout) {              // second result: act2 of the (bf16) first one, Cout % 8 == 0
             bf16x8 y;
+            if (a.act2 == ACT_GELU) {             // decided outside the element loop: a switch inside is a branch per element
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], a.act2);
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], ACT_GELU);
+            } else if (a.act2 == ACT_SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], ACT_SILU);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], a.act2);
+            }
             *(bf16x8*)(a.out2 + e) = y;
         }
     }
