@@ -239,7 +239,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
             const int co = co0 + c4 + j;
             const float v = s_red[(0 * ROWS + row) * 33 + c4 + j] + s_red[(1 * ROWS + row) * 33 + c4 + j] +
                             s_red[(2 * ROWS + row) * 33 + c4 + j] + s_red[(3 * ROWS + row) * 33 + c4 + j];
-            val[mb][j] = act_fwd(v + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f), a.act);
+            val[mb][j] = v + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
+        }
+        if (a.act != ACT_NONE) {             // (a convolution-side activation is the rare case: decided outside the element loop)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[mb][j] = act_fwd(val[mb][j], a.act);
         }
         if (live[mb]) {
             bf16x4 o;
