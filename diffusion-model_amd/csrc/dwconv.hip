@@ -101,9 +101,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const bf16* __rest
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) sb[j] = 0.f;
-    for (long long pix = p0 + prow; pix < p1; pix += pstep) {
-        const int wx = (int)(pix % W);
-        const int hy = (int)((pix / W) % H);
+    // (wx, hy) of the thread's first pixel by division, then advanced by pstep pixels per iteration with carries: two 64-bit
+    // divisions per pixel cost about as much as the pixel's 80 multiply-adds
+    long long pix = p0 + prow;
+    int wx = (int)(pix % W), hy = (int)((pix / W) % H);
+    const int step_y = pstep / W, step_x = pstep - step_y * W;
+    for (; pix < p1; pix += pstep, wx += step_x, hy += step_y) {
+        if (wx >= W) { wx -= W; ++hy; }
+        while (hy >= H) hy -= H;
         const bf16x8 g = *(const bf16x8*)(dy + pix * C + c);
         bf16x8 v[9];
 #pragma unroll

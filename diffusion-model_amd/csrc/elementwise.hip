@@ -416,23 +416,59 @@ __global__ __launch_bounds__(256) void train_head_kernel(const float* __restrict
     const long long chw = (long long)C * HW;
     const long long total4 = (long long)N * chw / 4;
     const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
-    for (long long q = gid; q < total4; q += gstride) {
-        const long long e = q * 4;
-        const int n = (int)(e / chw);
-        const int ti = (int)(t_in ? t_in[n] : draw_timestep(sd, n, T));
-        const float a = sched[ti * SC_STRIDE + SC_SQRT_AB], b = sched[ti * SC_STRIDE + SC_SQRT_1MAB];
-        const f32x4 x = *(const f32x4*)(x0 + e);
-        const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, 1u, (unsigned long long)q);
-        const long long r = e - (long long)n * chw;
-        const int c = (int)(r / HW);
-        const int p = (int)(r - (long long)c * HW);          // HW % 4 == 0: the four elements share n and c
+    if (cpad == 16) {
+        // images (C <= 16): a thread owns four pixels with all their channels and stores each pixel's 32 bytes (channels
+        // and zero padding) as two vectors; per-channel scalar stores would be 64 two-byte stores per thread
+        const int hw4 = HW / 4;
+        for (long long it = gid; it < (long long)N * hw4; it += gstride) {
+            const int n = (int)(it / hw4);
+            const int p = (int)(it - (long long)n * hw4) * 4;
+            const int ti = (int)(t_in ? t_in[n] : draw_timestep(sd, n, T));
+            const float a = sched[ti * SC_STRIDE + SC_SQRT_AB], b = sched[ti * SC_STRIDE + SC_SQRT_1MAB];
+            bf16x8 lo[4], hi[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float o = a * x[j] + b * z[j];             // two roundings + one, as q_sample_kernel (no FMA)
-            bf16* px = xt_nhwc + ((long long)n * HW + p + j) * cpad;
-            px[c] = (bf16)o;
-            if (c == 0)
-                for (int cc = C; cc < cpad; ++cc) px[cc] = (bf16)0.f;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { lo[j][k] = (bf16)0.f; hi[j][k] = (bf16)0.f; }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c < C) {
+                    const long long e = ((long long)n * C + c) * HW + p;
+                    const f32x4 x = *(const f32x4*)(x0 + e);
+                    const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, 1u, (unsigned long long)(e >> 2));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16 o = (bf16)(a * x[j] + b * z[j]);      // two roundings + one, as q_sample_kernel (no FMA)
+                        if (c < 8) lo[j][c & 7] = o; else hi[j][c & 7] = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16* px = xt_nhwc + ((long long)n * HW + p + j) * 16;
+                *(bf16x8*)px = lo[j];
+                *(bf16x8*)(px + 8) = hi[j];
+            }
+        }
+    } else {
+        for (long long q = gid; q < total4; q += gstride) {
+            const long long e = q * 4;
+            const int n = (int)(e / chw);
+            const int ti = (int)(t_in ? t_in[n] : draw_timestep(sd, n, T));
+            const float a = sched[ti * SC_STRIDE + SC_SQRT_AB], b = sched[ti * SC_STRIDE + SC_SQRT_1MAB];
+            const f32x4 x = *(const f32x4*)(x0 + e);
+            const f32x4 z = noise ? *(const f32x4*)(noise + e) : philox_normal4(sd, 1u, (unsigned long long)q);
+            const long long r = e - (long long)n * chw;
+            const int c = (int)(r / HW);
+            const int p = (int)(r - (long long)c * HW);          // HW % 4 == 0: the four elements share n and c
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o = a * x[j] + b * z[j];
+                bf16* px = xt_nhwc + ((long long)n * HW + p + j) * cpad;
+                px[c] = (bf16)o;
+                if (c == 0)
+                    for (int cc = C; cc < cpad; ++cc) px[cc] = (bf16)0.f;
+            }
         }
     }
     const int half = dim / 2;
@@ -463,7 +499,7 @@ extern "C" int ddpm_train_head(const float* x0, const int64_t* t_in, const float
     DDPM_REQUIRE(x0 && sched && t_out && xt_nhwc && sin_out && seed && done, "train_head: null pointer");
     DDPM_REQUIRE(N > 0 && C > 0 && HW > 0 && HW % 4 == 0 && cpad >= C && T > 0, "train_head: H*W must be a positive multiple of 4, cpad >= C");
     DDPM_REQUIRE(t_dim >= 4 && t_dim % 2 == 0, "train_head: bad embedding width %d", t_dim);
-    const long long total4 = (long long)N * C * HW / 4;
+    const long long total4 = cpad == 16 ? (long long)N * HW / 4 : (long long)N * C * HW / 4;
     hipLaunchKernelGGL(train_head_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream_, x0, (const long long*)t_in, noise,
                        sched, (long long*)t_out, (bf16*)xt_nhwc, cpad, (bf16*)sin_out, 1.0f / time_norm, t_dim, N, C, HW, T,
                        (unsigned long long*)seed, (unsigned*)done);
