@@ -261,6 +261,17 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / HW);
         const int p = (int)(i - (long long)n * HW);
+        if (cpad == 16) {             // images: the pixel's 32 bytes (channels + zero padding) as two vector stores
+            bf16x8 lo, hi;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                lo[c] = c < C ? (bf16)x[((long long)n * C + c) * HW + p] : (bf16)0.f;
+                hi[c] = c + 8 < C ? (bf16)x[((long long)n * C + c + 8) * HW + p] : (bf16)0.f;
+            }
+            *(bf16x8*)(out + i * 16) = lo;
+            *(bf16x8*)(out + i * 16 + 8) = hi;
+            continue;
+        }
         for (int c = 0; c < cpad; ++c) out[i * cpad + c] = c < C ? (bf16)x[((long long)n * C + c) * HW + p] : (bf16)0.f;
     }
 }
@@ -280,6 +291,22 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / HW);
         const int p = (int)(i - (long long)n * HW);
+        if (cpad == 16) {             // images: the pixel's 32 bytes as two vector stores
+            bf16x8 lo, hi;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float g = 0.f;
+                if (c < C) {
+                    const long long s = ((long long)n * C + c) * HW + p;
+                    const float yy = y[s];
+                    g = dy[s] * (1.0f - yy * yy);
+                }
+                if (c < 8) lo[c & 7] = (bf16)g; else hi[c & 7] = (bf16)g;
+            }
+            *(bf16x8*)(dz + i * 16) = lo;
+            *(bf16x8*)(dz + i * 16 + 8) = hi;
+            continue;
+        }
         for (int c = 0; c < cpad; ++c) {
             float g = 0.f;
             if (c < C) {
