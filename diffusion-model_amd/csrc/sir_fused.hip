@@ -373,8 +373,14 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
     SIR_STAMP(9);
 }
 
+// Waves per SIMD the register allocation must leave room for.  The 16x16 shape, whose natural allocation is 137
+// registers, is held to 128 (24 bytes of spills outside any loop) so that two workgroups share a CU: with one workgroup
+// per CU the latencies of its serial phases are exposed, and at sampling batch sizes there are several workgroups per CU
+// to overlap (4883 against 4688 sampled images/s).  The 8x8 / 4x4 shapes of wider networks spill more and showed no gain.
+constexpr int sir_fwd_waves(int c, int w) { return (c == 32 && w == 16) ? 4 : 2; }
+
 template <int C, int W>
-__global__ __launch_bounds__(SIR_THREADS) void sir_fwd_kernel(const SirArgs a) {
+__global__ __launch_bounds__(SIR_THREADS, sir_fwd_waves(C, W)) void sir_fwd_kernel(const SirArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     switch (a.act) {
         case ACT_GELU: sir_fwd_body<C, W, ACT_GELU>(a, smem); break;
