@@ -655,7 +655,12 @@ extern "C" int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int ns
     DDPM_REQUIRE(bytes && offsets && seed && nsites > 0 && total_bytes > 0 && total_bytes % 4 == 0, "dropout_masks: bad arguments");
     DDPM_REQUIRE(keep > 0.f && keep <= 1.f, "dropout_masks: keep probability %f out of range", (double)keep);
     const unsigned thresh = (unsigned)(keep * 65536.0f + 0.5f);
-    hipLaunchKernelGGL(dropout_masks_kernel, dim3(stream_grid(total_bytes / 4, 256)), dim3(256), 0, stream, bytes,
+    // At most two workgroups per CU: the kernel is ALU bound (70 us against 62 us with every wave slot taken, for 22 MB of
+    // bits), and it usually runs on a side stream beside latency-bound kernels whose workgroups must still find free
+    // wave slots (a full-size grid delayed the first kernels of a training step by ~50 us).
+    int mgrid = stream_grid(total_bytes / 4, 256);
+    if (mgrid > 512) mgrid = 512;
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3(mgrid), dim3(256), 0, stream, bytes,
                        (const long long*)offsets, nsites, (long long)total_bytes, thresh, (const unsigned long long*)seed);
     return ddpm_check_launch("dropout_masks");
 }

@@ -167,6 +167,7 @@ class UNetEngine:
         self.fuse_embed = True          # all time-embedding MLPs in one forward and one backward launch
         self.wgrad_tiles_per_split = 8  # grouped weight gradients: 128-position tiles per position split
         self.wgrad_tiles_last = 2       # the same for the last phase of a multi-phase backward, whose group launch runs alone
+        self.wgrad_tiles_by_phase = None
         self._cur_tps = 8
         self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together
         self._pin_eager: Optional[Tensor] = None      # pinned staging of the grouped-launch tables (eager steps reuse one)
@@ -1016,6 +1017,8 @@ class UNetEngine:
         middle stage.  Leaf work (weight gradients, partial-sum folds, time-embedding MLPs) is only queued here."""
         tape, out_holder, _, marks = ctx
         self._cur_tps = self.wgrad_tiles_last if (marks and phase == len(marks)) else self.wgrad_tiles_per_split
+        if self.wgrad_tiles_by_phase:
+            self._cur_tps = self.wgrad_tiles_by_phase[min(phase, len(self.wgrad_tiles_by_phase) - 1)]
         if phase == 0:
             if not self.external_zero:
                 self.grads.zero()

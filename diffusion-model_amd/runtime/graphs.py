@@ -176,6 +176,8 @@ class PipelinedTrainStep:
         import os
         self.eng.wgrad_tiles_last = int(os.environ.get("DDPM_TPS_LAST", self.eng.wgrad_tiles_last))
         self.eng.wgrad_tiles_per_split = int(os.environ.get("DDPM_TPS", self.eng.wgrad_tiles_per_split))
+        if os.environ.get("DDPM_TPS_PHASES"):
+            self.eng.wgrad_tiles_by_phase = [int(v) for v in os.environ["DDPM_TPS_PHASES"].split(",")]
         self.K, self.mid = self.eng.phase_layout()      # mid: the phase after which the decoder half of the gradients is final
         self.loss = torch.zeros(1, device=x0.device)
         self._head_done = torch.zeros(1, device=x0.device, dtype=torch.int32)      # ddpm_train_head's last-workgroup counter
