@@ -685,8 +685,31 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         if (threadIdx.x == 0) dst[e.dst_off] += (s[0][0] + s[0][1]) + (s[0][2] + s[0][3]);
         return;
     }
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     if (blockIdx.x * 64 >= e.width) return;
+    if (!((e.src_off | e.dst_off | e.row_stride | e.width) & 3)) {
+        // everything a multiple of 4 floats (all but a few odd-sized tensors): 16 column quads x 16 row lanes, so a thread
+        // keeps 16-byte loads of up to four rows in flight and the row loop is a quarter as long
+        __shared__ f32x4 s4[16][16];
+        const int cq = threadIdx.x & 15, rl16 = threadIdx.x >> 4;
+        const int c4 = blockIdx.x * 64 + cq * 4;
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < e.width) {
+            const float* p = src + e.src_off + c4;
+#pragma unroll 4
+            for (int r = rl16; r < e.rows; r += 16) acc4 += *(const f32x4*)(p + (long long)r * e.row_stride);
+        }
+        s4[rl16][cq] = acc4;
+        __syncthreads();
+        if (rl16 == 0 && c4 < e.width) {
+            f32x4 t = s4[0][cq];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t += s4[k][cq];
+            f32x4* d = (f32x4*)(dst + e.dst_off + c4);
+            *d = *d + t;
+        }
+        return;
+    }
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     float acc = 0.f;
     if (col < e.width) {

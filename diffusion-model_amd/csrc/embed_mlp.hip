@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdArgs a) {
     const int CS = C * 2 + 16, HS = H * 2 + 16;
     char* s_d = smem;                    // [32][CS] gradient of the MLP output, bf16
     char* s_z = smem + 32 * CS;          // [32][HS] gradient of the hidden pre-activation, bf16
+    // the hidden layer's column tiles (the long part: K = C, weight rows streamed from L2) are dealt over the gridDim.z
+    // workgroups of this (row block, MLP); each of them stages the output gradient for itself
+    const int gz = gridDim.z, bz = blockIdx.z;
+    if (4 * bz >= H / 32) return;               // a narrow MLP in a launch sized for a wide one: nothing left for this workgroup
     const float* dt = a.dtemb[m];
     bf16* dt16 = a.dt16[m];
     for (int i = tid; i < 32 * C; i += 256) {
@@ -125,18 +129,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdArgs a) {
         const float v = (n0 + row < a.N) ? dt[(long long)(n0 + row) * C + c] : 0.f;
         const bf16 b = (bf16)v;
         *(bf16*)(s_d + row * CS + c * 2) = b;
-        if (n0 + row < a.N) dt16[(long long)(n0 + row) * C + c] = b;
+        if (bz == 0 && n0 + row < a.N) dt16[(long long)(n0 + row) * C + c] = b;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {        // bias gradient of the second linear layer: column sums of this row tile
-        float s = 0.f;
-        for (int r = 0; r < 32; ++r) s += (float)*(const bf16*)(s_d + r * CS + c * 2);
-        a.db1[m][(long long)blockIdx.x * C + c] = s;
-    }
+    if (bz == 0)
+        for (int c = tid; c < C; c += 256) {    // bias gradient of the second linear layer: column sums of this row tile
+            float s = 0.f;
+            for (int r = 0; r < 32; ++r) s += (float)*(const bf16*)(s_d + r * CS + c * 2);
+            a.db1[m][(long long)blockIdx.x * C + c] = s;
+        }
     const bf16* w1d = a.w1d[m];
     const bf16* raw0 = a.raw0[m];
     bf16* dz = a.dz[m];
-    for (int nt = wave; nt < H / 32; nt += 4) {
+    for (int nt = wave + 4 * bz; nt < H / 32; nt += 4 * gz) {
         const int col = nt * 32 + (lane & 31);
         const f32x16 acc = tile_rt(s_d, CS, w1d + (long long)col * C, C, lane);
 #pragma unroll
@@ -152,7 +157,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdArgs a) {
         }
     }
     __syncthreads();
-    for (int c = tid; c < H; c += 256) {        // bias gradient of the first linear layer
+    for (int c = tid; c < H; c += 256) {        // bias gradient of the first linear layer (the columns this workgroup computed)
+        if (((c >> 7) % gz) != bz) continue;
         float s = 0.f;
         for (int r = 0; r < 32; ++r) s += (float)*(const bf16*)(s_z + r * HS + c * 2);
         a.db0[m][(long long)blockIdx.x * H + c] = s;
@@ -205,6 +211,6 @@ extern "C" int ddpm_embed_backward(const ddpm_embed_bwd_desc* d, ddpm_stream_t s
     const size_t lds = 32 * (size_t)(2 * cmax + 16) + 32 * (size_t)(4 * cmax + 16);
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ddpm_check_launch("embed_backward: raise dynamic LDS limit");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((d->N + 31) / 32, d->nmlp), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((d->N + 31) / 32, d->nmlp, cmax >= 256 ? 4 : cmax >= 128 ? 2 : 1), dim3(256), lds, stream, a);
     return ddpm_check_launch("embed_backward");
 }
