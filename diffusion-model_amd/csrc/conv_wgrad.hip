@@ -481,7 +481,12 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     if (d->tiles_per_split > 0) {
         // grouped launches fill the machine with many problems at once: fewer, longer position splits mean fewer
         // partial tiles to store and to fold afterwards
-        const long long want = (a.ntiles + d->tiles_per_split - 1) / d->tiles_per_split;
+        // (a tile of a stride-2 problem costs a workgroup about twice the time of any other tile - its patch holds four input
+        // pixels per position - and these problems are few, small workgroup chains that decide how long their launch lasts:
+        // half the tiles per split.  Measured on the whole step: 2.85 -> 2.82 ms; a quarter, or fewer tiles for the other
+        // 9-tap problems as well, is slower again because of the partial tiles to store and fold)
+        const int tps = d->kind == CONV_3X3_S2 ? (d->tiles_per_split + 1) / 2 : d->tiles_per_split;
+        const long long want = (a.ntiles + tps - 1) / tps;
         if (want < msplit) msplit = want;
     }
     if (msplit < 1) msplit = 1;

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libddpm_hip.so")
+LIB_PATH = os.environ.get("DDPM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libddpm_hip.so")     # (the variable: diagnostic builds)
 
 ACT = {"none": 0, None: 0, "gelu": 1, "silu": 2, "relu": 3, "tanh": 4, "sigmoid": 5, "hardsigmoid": 6, "relu6": 7, "leaky_relu": 8, "selu": 9,
        "swish": 10, "hardswish": 11}

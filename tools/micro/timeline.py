@@ -49,3 +49,6 @@ for k, (c, t) in sorted(shape.items(), key=lambda kv: -kv[1][1])[:60]:
 print("main queue, first kernels of the step:")
 for r in main[:34]:
     print(f"   {(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:8.1f}  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>8s}  {r['Kernel_Name'][:110]}")
+print("main queue, first and last kernels:")
+for r in main[:10] + main[-8:]:
+    print(f"   {(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:8.1f}  {r['Kernel_Name'][:70]}  grid {r.get('Grid_Size', r.get('Grid_Size_X', ''))}")
