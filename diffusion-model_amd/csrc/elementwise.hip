@@ -629,23 +629,44 @@ extern "C" int ddpm_spatial_sum(const void* x, float* out, int N, int HW, int C,
 }
 
 // Dropout keep bits for all sites of a step in one launch.  Byte b of site s holds the keep decisions of the
-// 8 consecutive elements 8b..8b+7 of that site's tensor; 16 bytes (128 elements) per thread.
+// 8 consecutive elements 8b..8b+7 of that site's tensor.  A thread writes 16 bytes (128 elements) per round with one
+// site look-up; only a 16-byte run that crosses into the next site (or the end of the buffer) looks its words up one by one.
 __global__ __launch_bounds__(256) void dropout_masks_kernel(unsigned char* __restrict__ bytes, const long long* __restrict__ offsets,
                                                              int nsites, long long total_bytes, unsigned thresh,
                                                              const unsigned long long* __restrict__ seed) {
     const unsigned long long sd = *seed;
-    // every site's byte range starts and ends on a multiple of 4, so a 4-byte word never straddles two sites
-    for (long long i = (blockIdx.x * 256ll + threadIdx.x) * 4; i < total_bytes; i += (long long)gridDim.x * 256 * 4) {
-        int lo = 0, hi = nsites - 1;            // last site whose offset <= i
+    auto site_of = [&](long long i) {           // last site whose offset <= i
+        int lo = 0, hi = nsites - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (offsets[mid] <= i) lo = mid; else hi = mid - 1;
         }
-        const long long rel = i - offsets[lo];
-        unsigned word = 0;
+        return lo;
+    };
+    // every site's byte range starts and ends on a multiple of 4, so a 4-byte word never straddles two sites
+    for (long long i = (blockIdx.x * 256ll + threadIdx.x) * 16; i < total_bytes; i += (long long)gridDim.x * 256 * 16) {
+        const int lo = site_of(i);
+        const long long end = lo + 1 < nsites ? offsets[lo + 1] : total_bytes;
+        if (i + 16 <= end) {
+            const long long rel = i - offsets[lo];
+            unsigned w[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) word |= dropout_keep8(sd, (unsigned)lo, (unsigned long long)(rel + b), thresh) << (8 * b);
-        *(unsigned*)(bytes + i) = word;
+            for (int k = 0; k < 4; ++k) {
+                w[k] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w[k] |= dropout_keep8(sd, (unsigned)lo, (unsigned long long)(rel + 4 * k + b), thresh) << (8 * b);
+            }
+            *(uint4*)(bytes + i) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (long long j = i; j < i + 16 && j < total_bytes; j += 4) {
+                const int s = site_of(j);
+                const long long rel = j - offsets[s];
+                unsigned word = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) word |= dropout_keep8(sd, (unsigned)s, (unsigned long long)(rel + b), thresh) << (8 * b);
+                *(unsigned*)(bytes + j) = word;
+            }
+        }
     }
 }
 
@@ -654,11 +675,12 @@ extern "C" int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int ns
     hipStream_t stream = (hipStream_t)stream_;
     DDPM_REQUIRE(bytes && offsets && seed && nsites > 0 && total_bytes > 0 && total_bytes % 4 == 0, "dropout_masks: bad arguments");
     DDPM_REQUIRE(keep > 0.f && keep <= 1.f, "dropout_masks: keep probability %f out of range", (double)keep);
+    DDPM_REQUIRE(((uintptr_t)bytes & 15) == 0, "dropout_masks: the bit buffer must be 16-byte aligned");
     const unsigned thresh = (unsigned)(keep * 65536.0f + 0.5f);
     // At most two workgroups per CU: the kernel is ALU bound (70 us against 62 us with every wave slot taken, for 22 MB of
     // bits), and it usually runs on a side stream beside latency-bound kernels whose workgroups must still find free
     // wave slots (a full-size grid delayed the first kernels of a training step by ~50 us).
-    int mgrid = stream_grid(total_bytes / 4, 256);
+    int mgrid = stream_grid((total_bytes + 15) / 16, 256);
     if (mgrid > 512) mgrid = 512;
     hipLaunchKernelGGL(dropout_masks_kernel, dim3(mgrid), dim3(256), 0, stream, bytes,
                        (const long long*)offsets, nsites, (long long)total_bytes, thresh, (const unsigned long long*)seed);
