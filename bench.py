@@ -113,7 +113,8 @@ def dropin_eager(dev, channels, size, batch, micro_steps=9):
     dt = (time.perf_counter() - t0) / micro_steps
     return {"value": batch / dt, "unit": "images/s", "ms_per_micro_step": 1e3 * dt, "gradient_accumulation_steps": 3,
             "what": "the reference trainer's loop (randint, q, model, criterion, backward(retain_graph), step every 3rd) on the module "
-                    "surface without a graph driver: host-launch bound"}
+                    "surface without a graph driver: the module replays its own captured forward / backward graphs from the second "
+                    "pass of a shape on"}
 
 
 def timed(step_fn, steps, warmup, barrier, dist, dev):

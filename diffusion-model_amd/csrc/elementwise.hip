@@ -543,6 +543,29 @@ extern "C" int ddpm_bump_seed(uint64_t* seed_, ddpm_stream_t stream_) {
     return ddpm_check_launch("bump_seed");
 }
 
+// Range check of a timestep vector without stalling the host: safe[i] = t[i] clamped into [lo, hi] (what the kernels that
+// index the per-timestep table then read), and for an out-of-range value flag[0] = 1, flag[1] = that value (saturated to
+// 32 bits).  flag lives in host-pinned memory: the host looks at it whenever it likes, never waiting for the device.
+__global__ __launch_bounds__(256) void check_timesteps_kernel(const long long* __restrict__ t, long long* __restrict__ safe, int n, int lo,
+                                                               int hi, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long v = t[i];
+    if (v < lo || v > hi) {
+        flag[1] = v < -2147483647ll ? -2147483647 : v > 2147483647ll ? 2147483647 : (int)v;
+        flag[0] = 1;
+    }
+    safe[i] = v < lo ? lo : v > hi ? hi : v;
+}
+
+extern "C" int ddpm_check_timesteps(const int64_t* t, int64_t* safe, int n, int lo, int hi, int32_t* flag, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(t && safe && flag && n > 0 && lo <= hi, "check_timesteps: bad arguments");
+    hipLaunchKernelGGL(check_timesteps_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const long long*)t, (long long*)safe, n, lo, hi,
+                       (int*)flag);
+    return ddpm_check_launch("check_timesteps");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column sums of an NHWC bf16 matrix [rows][cs] -> fp32 [C] (+=): the bias gradient of a convolution whose
 // output gradient is not produced by a GroupNorm backward (the image head, the time-embedding MLPs).

@@ -79,15 +79,37 @@ class DDPM(nn.Module):
         if not x.is_cuda:
             raise RuntimeError(f"DDPM.{what} runs on the HIP kernels only: tensors must live on an MI355X (cuda) device")
 
-    def _check_t(self, t: Tensor, lo: int, what: str) -> None:
-        """The kernels index the per-timestep table with t unchecked; the reference's table lookup raises IndexError for an
-        out-of-range timestep.  Checked on the host (one small device-to-host read) except inside a graph capture, whose
-        timesteps come from this module's own generators."""
+    def _check_t(self, t: Tensor, lo: int, what: str) -> Tensor:
+        """The kernels index the per-timestep table with t; the reference's table look-up raises IndexError for a timestep
+        outside the schedule.  Here a small kernel clamps t into [lo, T] (returned: what the caller's kernels read, so no
+        launch ever indexes outside the table) and reports an out-of-range value through two words of pinned host memory.
+        The host never waits for the device: the IndexError is raised by the next call that checks (q, reverse_q,
+        check_timesteps), i.e. one call late when the device is still busy.  A synchronous check costs the drop-in training
+        loop a full host/device rendezvous per micro-batch.  Skipped inside a graph capture, whose timesteps come from this
+        module's own generators."""
         if torch.cuda.is_current_stream_capturing() or t.numel() == 0:
+            return t
+        self.check_timesteps()
+        if getattr(self, "_t_flag", None) is None or not self._t_flag.is_pinned():      # (a deep copy of the module unpins it)
+            self._t_flag = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._t_what = ""
+        safe = torch.empty_like(t)
+        hip.call("ddpm_check_timesteps", hip.ptr(t), hip.ptr(safe), t.numel(), lo, self.T, self._t_flag.data_ptr(), hip.stream())
+        self._t_what = f"DDPM.{what}: timesteps must lie in [{lo}, {self.T}]"
+        return safe
+
+    def check_timesteps(self, wait: bool = False) -> None:
+        """Raise the IndexError of an earlier q / reverse_q call that was handed a timestep outside the schedule (see _check_t);
+        wait=True first waits for the device, so that every call made so far has been checked."""
+        flag = getattr(self, "_t_flag", None)
+        if flag is None:
             return
-        mn, mx = (int(v) for v in torch.aminmax(t))
-        if mn < lo or mx > self.T:
-            raise IndexError(f"DDPM.{what}: timesteps must lie in [{lo}, {self.T}], got [{mn}, {mx}]")
+        if wait:
+            torch.cuda.synchronize()
+        if int(flag[0]) != 0:
+            bad = int(flag[1])
+            flag.zero_()
+            raise IndexError(f"{self._t_what}, got {bad}")
 
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -97,7 +119,7 @@ class DDPM(nn.Module):
         x_0 = x_0.float().contiguous()
         n, c, h, w = x_0.shape
         t = T.to(torch.long).contiguous()
-        self._check_t(t, 0, "q")
+        t = self._check_t(t, 0, "q")
         out = torch.empty_like(x_0)
         tab = self.schedule_table(x_0.device)
         if noise is not None:
@@ -137,7 +159,7 @@ class DDPM(nn.Module):
         x_t = x_t.float().contiguous()
         x0_predicted = x0_predicted.float().contiguous()
         t = T.to(torch.long).contiguous()
-        self._check_t(t, 1, "reverse_q")
+        t = self._check_t(t, 1, "reverse_q")
         n = x_t.shape[0]
         chw = x_t.numel() // n
         if out is None:

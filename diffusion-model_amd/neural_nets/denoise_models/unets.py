@@ -122,16 +122,140 @@ def _int_list(v) -> List[int]:
     return [int(x) for x in v]
 
 
+class _Token:
+    """lives as long as the autograd node of one forward call (weakly referenced by the graph entry that served the call)"""
+    __slots__ = ("__weakref__",)
+
+
+# Graphs of entries that died, parked until a call that is known not to run inside a stream capture destroys them: an
+# entry may be released by the garbage collector at any allocation, also in the middle of someone else's capture, where
+# destroying a graph is a fatal error of the runtime.
+_RETIRED_GRAPHS: list = []
+
+
+class _GraphEntry:
+    """The forward pass and the backward pass of ONE (batch shape, mode, parameter storage) as two HIP graphs that share a
+    memory pool, replayed by the module's ordinary autograd path.
+
+    A caller that drives the module the way the reference trainer does (model(x, t) ... loss.backward(), no graph driver)
+    pays ~150 kernel launches per step from Python, which is several times the device time of the step.  After one eager
+    pass of a shape (it sizes the engine's workspaces and sets pinned staging buffers aside) the module captures the pass
+    and from then on a call costs two small copies and one graph launch.  Inputs and the output gradient are copied into
+    static buffers; the prediction is returned as a copy; parameter gradients are returned as views of a fresh copy of the
+    engine's staging buffer, so autograd may keep or accumulate them.  Everything that changes between calls lives in
+    device memory (dropout seeds advance by kernels, the kernel-layout weight copies are refreshed inside the graph)."""
+
+    def __init__(self, module: "BaseUNet", x: Tensor, time: Tensor, record: bool, flat_params):
+        # (no reference to the module: the entry must die with it by reference count.  A cycle would leave the graphs to the
+        # garbage collector, which may run inside someone else's stream capture, and destroying a graph there is fatal)
+        self.record = record
+        self.eng = eng = module._get_engine()
+        self.names = module._param_names
+        self.params = dict(zip(self.names, flat_params))
+        self.x = x.clone()
+        self.t = time.clone()
+        self.pending = False
+        self.live = None
+        self.g_b = self.dout = self.last_flat = None
+        self.plist = list(flat_params)
+        repack, eng.always_repack = eng.always_repack, True           # the weight re-layout becomes a node of the graph
+        try:
+            self.g_f = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_f, capture_error_mode="thread_local"):
+                self.out, self.tape = eng.forward(self.params, self.x, self.t, train=module.training, record=record)
+        finally:
+            eng.always_repack = repack
+        # engine-owned buffers the graphs address: they stay alive with the entry even if the engine replaces them later
+        self.keep = [eng._zero_arena, eng.grads.flat if eng.grads is not None else None, eng.grads.flat_t if eng.grads is not None else None]
+
+    def __del__(self):
+        _RETIRED_GRAPHS.append((getattr(self, "g_f", None), getattr(self, "g_b", None)))
+
+    def usable(self) -> bool:
+        """not while an earlier call's autograd graph may still run its backward on the static buffers"""
+        return not (self.pending and self.live is not None and self.live() is not None)
+
+    def forward(self, x: Tensor, time: Tensor):
+        self.x.copy_(x)
+        self.t.copy_(time)
+        self.g_f.replay()
+        tok = None
+        if self.record:
+            import weakref
+            tok = _Token()
+            self.live, self.pending = weakref.ref(tok), True
+        return self.out.clone(), tok
+
+    def backward(self, dout: Tensor):
+        eng = self.eng
+        if self.g_b is None:
+            self.dout = dout.contiguous().clone()
+            self.g_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_b, pool=self.g_f.pool(), capture_error_mode="thread_local"):
+                eng.backward(self.tape, self.dout, self.params, unpack=False)
+            self.keep += [eng._zero_arena, eng.grads.flat, eng.grads.flat_t]
+            lay = eng.grads.tlayout
+            self.sizes, self.shapes = [], []
+            cursor = 0
+            for k in self.names:                        # parameters in registration order, each padded to 4 elements
+                o, shp = lay[k]
+                assert o == cursor, "gradient staging layout is not the parameters in registration order"
+                n = 1
+                for d in shp:
+                    n *= d
+                self.sizes.append((n + 3) // 4 * 4)
+                self.shapes.append((n, tuple(shp)))
+                cursor += self.sizes[-1]
+            self.total = cursor
+        else:
+            self.dout.copy_(dout)
+        self.g_b.replay()
+        self.pending = False
+        fresh = eng.grads.flat_t[:self.total]
+        prev, plist = self.last_flat, self.plist
+        if prev is not None and self._accumulating_into(prev, plist):
+            # a later micro-batch of a gradient-accumulation window: every .grad is still the view of the buffer the previous
+            # call returned.  autograd would now add the 350 new tensors to them one launch each; instead the sum is formed
+            # here by ONE launch and handed over as this call's gradients, with .grad cleared so that autograd adopts the
+            # tensors as they are (hooks on the accumulation step, DistributedDataParallel's among them, run as ever and
+            # find the same .grad they would have found)
+            flat = torch.add(prev, fresh)
+            for q in plist:
+                q.grad = None
+        else:
+            flat = fresh.clone()
+        self.last_flat = flat
+        return tuple(piece.view(shp) if piece.numel() == n else piece[:n].view(shp)
+                     for piece, (n, shp) in zip(flat.split_with_sizes(self.sizes), self.shapes))
+
+    def _accumulating_into(self, prev: Tensor, plist) -> bool:
+        base, off = prev.data_ptr(), 0
+        for q, size, (n, shp) in zip(plist, self.sizes, self.shapes):
+            g = q.grad
+            if g is None or g.data_ptr() != base + 4 * off or g.dtype != torch.float32 or tuple(g.shape) != shp or q._backward_hooks:
+                return False
+            off += size
+        return True
+
+
 class _UNetFn(torch.autograd.Function):
     """One autograd node for the whole denoiser: forward runs the fused program, backward replays its tape."""
 
     @staticmethod
     def forward(ctx, module: "BaseUNet", record: bool, x: Tensor, time: Tensor, *flat_params: Tensor):
         eng = module._get_engine()
-        params = dict(zip(module._param_names, flat_params))
         ctx.set_materialize_grads(False)
+        ctx.module, ctx.entry, ctx.key = module, None, None
+        entry, key = module._graph_entry(x, time, record, flat_params)
+        if entry is not None:
+            out, ctx.token = entry.forward(x, time)
+            ctx.entry, ctx.tape = entry, (entry if record else None)
+            return out
+        params = dict(zip(module._param_names, flat_params))
         out, tape = eng.forward(params, x, time, train=module.training, record=record, taps=module._taps)
-        ctx.tape, ctx.module = tape, module
+        ctx.tape, ctx.key = tape, key
+        if key is not None and not record:
+            module._graph_seen[key] = module._graph_seen.get(key, 0) + 1
         return out
 
     @staticmethod
@@ -139,10 +263,16 @@ class _UNetFn(torch.autograd.Function):
         module = ctx.module
         if ctx.tape is None or dout is None:
             return (None, None, None, None) + (None,) * len(module._param_names)
+        if ctx.entry is not None:
+            grads = ctx.entry.backward(dout)
+            ctx.tape = None
+            return (None, None, None, None) + grads
         eng = module._get_engine()
-        params = dict(zip(module._param_names, [p for p in module.parameters()]))
+        params = dict(zip(module._param_names, module._parameter_list()))
         grads = eng.backward(ctx.tape, dout, params)
         ctx.tape = None
+        if ctx.key is not None:                          # one complete eager pass of this shape: the next one is captured
+            module._graph_seen[ctx.key] = module._graph_seen.get(ctx.key, 0) + 1
         return (None, None, None, None) + tuple(grads[k] for k in module._param_names)
 
 
@@ -197,6 +327,13 @@ class BaseUNet(nn.Module):
         self._param_names: List[str] = names
         self._engine = None
         self._taps = None
+        self._param_slots = None
+        import os
+        # the autograd path replays captured HIP graphs from the second call of a shape on (see _GraphEntry); set to False
+        # (or DDPM_MODULE_GRAPHS=0) to launch every kernel from Python on every call
+        self.use_graphs = os.environ.get("DDPM_MODULE_GRAPHS", "1") != "0"
+        self._graphs: Dict[tuple, _GraphEntry] = {}
+        self._graph_seen: Dict[tuple, int] = {}
 
     # the engine holds device caches only; it is rebuilt on demand (after deepcopy / .to() / unpickling)
     def _get_engine(self) -> UNetEngine:
@@ -204,8 +341,32 @@ class BaseUNet(nn.Module):
             self._engine = UNetEngine(self.spec)
         return self._engine
 
+    def _graph_entry(self, x: Tensor, time: Tensor, record: bool, flat_params):
+        """(captured entry to serve this call with, or None for the eager path; key under which an eager pass is counted)"""
+        if (not self.use_graphs or self._taps is not None or not flat_params or not x.is_cuda or x.dim() != 4
+                or torch.cuda.is_current_stream_capturing()):
+            return None, None
+        if _RETIRED_GRAPHS:               # (not capturing here: a safe place to destroy the graphs of dead entries)
+            _RETIRED_GRAPHS.clear()
+        eng = self._get_engine()
+        if eng.mask_ahead:                # a pipelined driver draws this engine's dropout bits one step ahead
+            return None, None
+        key = (tuple(x.shape), x.device.index, self.training, record, flat_params[0].data_ptr(), flat_params[-1].data_ptr(), eng.phases)
+        e = self._graphs.get(key)
+        if e is None:
+            if self._graph_seen.get(key, 0) < 1:
+                return None, key
+            if not x.is_contiguous() or time.dtype != torch.long or time.dim() != 1:
+                return None, None
+            while len(self._graphs) >= 3:              # a few shapes / modes at most stay captured (each holds its activations)
+                self._graphs.pop(next(iter(self._graphs)))
+            e = self._graphs[key] = _GraphEntry(self, x, time, record, flat_params)
+        return (e if e.usable() else None), None
+
     def __deepcopy__(self, memo):
         eng, self._engine = self._engine, None
+        graphs, seen, self._graphs, self._graph_seen = self._graphs, self._graph_seen, {}, {}
+        slots, self._param_slots = self._param_slots, None
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -215,17 +376,35 @@ class BaseUNet(nn.Module):
                 setattr(new, k, copy.deepcopy(v, memo))
         finally:
             self._engine = eng
+            self._graphs, self._graph_seen = graphs, seen
+            self._param_slots = slots
         return new
 
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None
+        st["_graphs"], st["_graph_seen"] = {}, {}
+        st["_param_slots"] = None
         return st
+
+    def _parameter_list(self) -> List[Tensor]:
+        """The parameters in registration order, read from the containers' own tables: nn.Module.parameters() walks the module
+        tree with its bookkeeping on every call (~0.9 ms for the 350 tensors), which a training loop pays per micro-batch."""
+        if self._param_slots is None:
+            slots = []
+            for name in self._param_names:
+                mod = self
+                *path, leaf = name.split(".")
+                for part in path:
+                    mod = mod._modules[part]
+                slots.append((mod._parameters, leaf))
+            self._param_slots = slots
+        return [table[leaf] for table, leaf in self._param_slots]
 
     def forward(self, input: Tensor, time: Tensor, *args, **kwargs) -> Tensor:
         if not input.is_cuda:
             raise RuntimeError("BaseUNet runs on the HIP kernels only: move the module and its inputs to an MI355X (cuda) device")
-        params = [p for p in self.parameters()]
+        params = self._parameter_list()
         # grad mode is off inside Function.forward, so decide here whether the tape must be recorded
         record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _UNetFn.apply(self, record, input.float(), time, *params)

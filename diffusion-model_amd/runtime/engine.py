@@ -1005,10 +1005,14 @@ class UNetEngine:
         cuts = self._phase_cuts(len(self.spec.stages))
         return len(cuts) + 1, sum(1 for c in cuts if c.startswith("dec") and c != "dec")
 
-    def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor]) -> Dict[str, Tensor]:
-        """Replay the tape in reverse; returns {parameter name: fp32 gradient in torch layout}."""
+    def backward(self, ctx, dout: Tensor, params: Dict[str, Tensor], unpack: bool = True) -> Optional[Dict[str, Tensor]]:
+        """Replay the tape in reverse; returns {parameter name: fp32 gradient in torch layout}.  unpack=False (callers that
+        capture the pass in a graph): the gradients are left in the gradient store's staging buffer (grads.flat_t)."""
         for ph in range(len(ctx[3]) + 1):
             self.backward_phase(ctx, ph, dout if ph == 0 else None)
+        if not unpack:
+            self.grads.unpack_staging()
+            return None
         return self.grads.unpack()
 
     def backward_data(self, ctx, phase: int, dout: Optional[Tensor] = None) -> None:

@@ -119,6 +119,7 @@ _PROTOS = {
     "ddpm_nhwc_bf16_to_nchw_f32": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_tanh_bwd_nchw_to_nhwc": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_bump_seed": ([_vp, _vp], _i),
+    "ddpm_check_timesteps": ([_vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "ddpm_sample_timesteps": ([_vp, _i, _i, _vp, _u32, _vp], _i),
     "ddpm_act_backward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "ddpm_prepare_images": ([_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp], _i),

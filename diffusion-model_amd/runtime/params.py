@@ -219,6 +219,12 @@ class GradStore:
         .grad must consume them before the next backward pass overwrites the buffer)"""
         return {k: self.flat_t[o:o + _numel(shp)].view(shp) for k, (o, shp) in self.tlayout.items()}
 
+    def unpack_staging(self) -> Tensor:
+        """kernel layout -> torch layout for all parameters in one launch, into the persistent staging buffer (returned):
+        the next backward pass overwrites it."""
+        hip.call("ddpm_remap", hip.ptr(self._table), hip.ptr(self._chunks), self._n, 0, hip.stream())
+        return self.flat_t
+
     def unpack(self) -> Dict[str, Tensor]:
         """kernel layout -> torch layout for all parameters in one launch; returns {name: gradient}.  The gradients are
         views of ONE freshly allocated flat buffer (a copy of the staging buffer), so a caller - autograd's accumulation

@@ -92,6 +92,10 @@ int ddpm_nhwc_bf16_to_nchw_f32(const void* x, float* out, int N, int C, int HW, 
 int ddpm_tanh_bwd_nchw_to_nhwc(const float* dy, const float* y, void* dz, int N, int C, int HW, int cpad, ddpm_stream_t stream);
 /* *seed += odd constant: lets a replayed HIP graph draw fresh randomness every step. */
 int ddpm_bump_seed(uint64_t* seed, ddpm_stream_t stream);
+/* Range check of the per-image timesteps (the reference's table look-ups raise IndexError for a timestep outside the
+ * schedule, ddpm.py:46-66,159-201 there) that does not stall the host: safe[i] = t[i] clamped into [lo, hi], and an
+ * out-of-range value sets flag[0] = 1, flag[1] = the value.  flag: two int32 in host-pinned (device-visible) memory. */
+int ddpm_check_timesteps(const int64_t* t, int64_t* safe, int n, int lo, int hi, int32_t* flag, ddpm_stream_t stream);
 /* Backward of the bare activation of a conv -> act unit without normalisation (conv_block.py:19-54 with norm = None):
  * dx = dy * act'(x) on NHWC bf16 [N][HW][C] (C = 8, 16, 32 or 64), and part[(n * P + p)][C] = column sums of dx over the
  * p-th of P equal pixel ranges of image n (partial rows of the convolution's bias gradient; P must divide HW). */

@@ -174,3 +174,30 @@ def test_train_head_equals_the_separate_kernels(dev, n, c, h):
         assert torch.equal(x_out, x_ref)
         assert torch.equal(s_out, s_ref)
         assert torch.equal(seed_a, seed_b)
+
+
+def test_timestep_range_check_does_not_stall_and_raises(dev):
+    """A timestep outside the schedule raises IndexError as the reference's table look-up does (ddpm.py:46-66 there), without
+    a host/device rendezvous per call: the offending call computes with the timestep clamped into range, and the error is
+    raised by the next checking call (or by check_timesteps(wait=True))."""
+    from dm_amd.neural_nets.denoise_models import ddpm as dm_ddpm, unets as dm_unets
+    m = dm_ddpm.DDPM(dm_unets.BaseUNet, stages_channels=[32, 64, 128, 256], expand_factor=2, drop_p=0.0, T=120, beta=0.25,
+                     t_embed_dim=32, activation="gelu", base_groups_norm=4, initializer="he_normal", dtype=None,
+                     is_conditional=False, img_channels=1, reconstruction_method="mse", latent_dim=512, device=dev).to(dev)
+    x = torch.rand(3, 1, 32, 32, device=dev)
+    noise = torch.randn(3, 1, 32, 32, device=dev)
+    ok = torch.tensor([0, 60, 120], device=dev)
+    a = m.q(x, ok, noise=noise)
+    m.check_timesteps(wait=True)                                   # nothing pending
+    assert torch.equal(a[0], x[0])                                 # t = 0 is the identity (fw_mean_coef[0] = 1, fw_std[0] = 0)
+    bad = torch.tensor([5, 121, 7], device=dev)
+    b = m.q(x, bad, noise=noise)                                   # computes with 121 clamped to 120
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="121"):
+        m.q(x, ok, noise=noise)
+    m.check_timesteps(wait=True)                                   # the flag was cleared by the raise
+    c = m.q(x, torch.tensor([5, 120, 7], device=dev), noise=noise)
+    assert torch.equal(b, c)
+    m.reverse_q(x, x, torch.tensor([0, 3, 4], device=dev), noise=noise)     # the reverse step starts at t = 1
+    with pytest.raises(IndexError):
+        m.check_timesteps(wait=True)

@@ -689,3 +689,77 @@ def test_sampling_noise_is_keyed_by_global_image_index(dev):
     torch.cuda.synchronize()
     assert torch.equal(out2, torch.cat([a, b]))
     assert not torch.equal(out, out2)                      # consecutive chains of one job differ
+
+
+def test_module_autograd_path_replays_captured_graphs(dev):
+    """From the second complete pass of a shape on, the module's ordinary autograd path (model(x, t) ... backward(), what the
+    reference trainer's loop calls) replays two captured HIP graphs instead of launching every kernel from Python: the same
+    prediction bit for bit and the same gradients to the rounding of their sums as the eager pass; gradients accumulate over
+    micro-batches like autograd's; a second forward while the first one's backward is still pending falls back to the
+    eager path; a parameter update is seen by the next replay."""
+    m, cfg, p = build(dev, 1, "gelu")
+    m.train()                                    # drop_p = 0: train mode without randomness
+    unet = m.model
+    assert unet.use_graphs
+    n = 4
+    x0 = (hash_uniform((n, 1, 32, 32), 31) * 2 - 1).to(dev)
+    t = torch.tensor([3, 40, 77, 120], device=dev)
+    crit = ELBOLoss("mse")
+
+    def one_pass(x0_):
+        m.zero_grad(set_to_none=True)
+        pred = m(x0_, t)
+        loss = crit(m, t, pred, x0_)["Loss"]
+        loss.backward(retain_graph=True)
+        return pred.detach().clone(), [q.grad.detach().clone() for q in m.parameters()]
+
+    pred_e, grads_e = one_pass(x0)               # eager (first pass of the shape)
+    assert not unet._graphs
+    pred_g, grads_g = one_pass(x0)               # captured here
+    assert len(unet._graphs) == 1
+    entry = next(iter(unet._graphs.values()))
+    assert entry.g_b is not None
+    pred_r, grads_r = one_pass(x0)               # replayed
+    for got in (pred_g, pred_r):
+        assert torch.equal(got, pred_e)
+    # (gradients: a few reductions of the backward pass add in an order that is not fixed from launch to launch, so two passes
+    # over the same numbers agree to fp32 rounding of the sums, not always bit for bit)
+    for (k, _), ge, gg, gr in zip(m.named_parameters(), grads_e, grads_g, grads_r):
+        scale = ge.abs().max().item() + 1e-30
+        assert (ge - gg).abs().max().item() <= 1e-4 * scale and (ge - gr).abs().max().item() <= 1e-4 * scale, k
+    # another input through the same graphs against the oracle's numbers
+    x1 = (hash_uniform((n, 1, 32, 32), 32) * 2 - 1).to(dev)
+    pred1, grads1 = one_pass(x1)
+    with torch.no_grad():
+        ref = O.unet_forward(p, cfg, x1.cpu(), t.cpu())
+    assert l2_err(pred1.cpu(), ref) < 5e-2
+    assert not torch.equal(pred1, pred_e)
+    # accumulation over two micro-batches = sum of the two gradients
+    m.zero_grad(set_to_none=True)
+    for xb in (x0, x1):
+        crit(m, t, m(xb, t), xb)["Loss"].backward()
+    for q, a, b in zip(m.parameters(), grads_e, grads1):
+        assert (q.grad - (a + b)).abs().max().item() <= 1e-4 * ((a + b).abs().max().item() + 1e-30)
+    # two forwards in flight: the second runs eagerly, both backward passes are right
+    m.zero_grad(set_to_none=True)
+    la = crit(m, t, m(x0, t), x0)["Loss"]
+    assert entry.pending
+    lb = crit(m, t, m(x1, t), x1)["Loss"]
+    (la + lb).backward()
+    for q, a, b in zip(m.parameters(), grads_e, grads1):
+        assert (q.grad - (a + b)).abs().max().item() <= 1e-4 * ((a + b).abs().max().item() + 1e-30)
+    # a parameter update reaches the next replay (weight copies are refreshed inside the graph)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.mul_(1.01)
+    pred2, _ = one_pass(x0)
+    assert len(unet._graphs) == 1 and not torch.equal(pred2, pred_e)
+    unet.use_graphs = False
+    pred3, _ = one_pass(x0)
+    unet.use_graphs = True
+    assert torch.equal(pred2, pred3)
+    # eval / no_grad calls get their own forward-only entry
+    m.eval()
+    with torch.no_grad():
+        a = m(x0, t); b = m(x0, t); c = m(x0, t)
+    assert torch.equal(a, b) and torch.equal(a, c) and len(unet._graphs) == 2
