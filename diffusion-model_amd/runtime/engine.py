@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -990,6 +992,8 @@ class UNetEngine:
         ph, mid = self.phases, nst // 2
         if ph <= 1:
             return set()
+        if os.environ.get("DDPM_PHASE_CUTS"):
+            return set(os.environ["DDPM_PHASE_CUTS"].split(","))
         if ph == 2:
             return {"dec"}
         if ph == 4:
