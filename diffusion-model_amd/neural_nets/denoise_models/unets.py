@@ -127,6 +127,11 @@ class _Token:
     __slots__ = ("__weakref__",)
 
 
+# Backward phases of a pass that goes through the module's autograd node (the engine's default is one): with its own graphs
+# the module runs the leaf work of a phase on a side stream beside the next phase's data-gradient chain, as the pipelined
+# driver does.
+_MODULE_PHASES = 4
+
 # Graphs of entries that died, parked until a call that is known not to run inside a stream capture destroys them: an
 # entry may be released by the garbage collector at any allocation, also in the middle of someone else's capture, where
 # destroying a graph is a fatal error of the runtime.
@@ -159,12 +164,13 @@ class _GraphEntry:
         self.g_b = self.dout = self.last_flat = None
         self.plist = list(flat_params)
         repack, eng.always_repack = eng.always_repack, True           # the weight re-layout becomes a node of the graph
+        phases, eng.phases = eng.phases, _MODULE_PHASES
         try:
             self.g_f = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_f, capture_error_mode="thread_local"):
                 self.out, self.tape = eng.forward(self.params, self.x, self.t, train=module.training, record=record)
         finally:
-            eng.always_repack = repack
+            eng.always_repack, eng.phases = repack, phases
         # engine-owned buffers the graphs address: they stay alive with the entry even if the engine replaces them later
         self.keep = [eng._zero_arena, eng.grads.flat if eng.grads is not None else None, eng.grads.flat_t if eng.grads is not None else None]
 
@@ -189,10 +195,28 @@ class _GraphEntry:
     def backward(self, dout: Tensor):
         eng = self.eng
         if self.g_b is None:
+            # The backward pass as the engine's phases: per phase a graph with the data-gradient chain (replayed on the
+            # caller's stream) and a graph with the phase's leaf work - weight gradients, partial-sum folds, time-embedding
+            # MLPs, finally the gradients' re-layout - replayed on a side stream beside the next phase's chain.  Every graph
+            # has a memory pool of its own, so nothing a leaf graph still reads is handed to a later chain's allocations.
+            from ...runtime.graphs import _pool_stream
             self.dout = dout.contiguous().clone()
-            self.g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_b, pool=self.g_f.pool(), capture_error_mode="thread_local"):
-                eng.backward(self.tape, self.dout, self.params, unpack=False)
+            self.side = _pool_stream(self.dout.device, 0)
+            nph = len(self.tape[3]) + 1
+            self.events = [torch.cuda.Event() for _ in range(nph + 1)]
+            chains, leaves = [], []
+            for ph in range(nph):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    eng.backward_data(self.tape, ph, self.dout if ph == 0 else None)
+                chains.append(g)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
+                    eng.backward_flush(self.tape, ph)
+                    if ph == nph - 1:
+                        eng.grads.unpack_staging()
+                leaves.append(g)
+            self.g_b = (chains, leaves)
             self.keep += [eng._zero_arena, eng.grads.flat, eng.grads.flat_t]
             lay = eng.grads.tlayout
             self.sizes, self.shapes = [], []
@@ -209,7 +233,15 @@ class _GraphEntry:
             self.total = cursor
         else:
             self.dout.copy_(dout)
-        self.g_b.replay()
+        main = torch.cuda.current_stream()
+        for ph, (chain, leaf) in enumerate(zip(*self.g_b)):
+            chain.replay()
+            self.events[ph].record(main)
+            self.side.wait_event(self.events[ph])
+            with torch.cuda.stream(self.side):
+                leaf.replay()
+        self.events[-1].record(self.side)
+        main.wait_event(self.events[-1])
         self.pending = False
         fresh = eng.grads.flat_t[:self.total]
         prev, plist = self.last_flat, self.plist
@@ -252,7 +284,13 @@ class _UNetFn(torch.autograd.Function):
             ctx.entry, ctx.tape = entry, (entry if record else None)
             return out
         params = dict(zip(module._param_names, flat_params))
-        out, tape = eng.forward(params, x, time, train=module.training, record=record, taps=module._taps)
+        phases = eng.phases
+        if module.use_graphs:             # every pass of the module takes the backward phases its captured passes take: the first
+            eng.phases = _MODULE_PHASES   # pass of a (shape, phases) sizes the engine's workspaces, which no capture may do
+        try:
+            out, tape = eng.forward(params, x, time, train=module.training, record=record, taps=module._taps)
+        finally:
+            eng.phases = phases
         ctx.tape, ctx.key = tape, key
         if key is not None and not record:
             module._graph_seen[key] = module._graph_seen.get(key, 0) + 1
