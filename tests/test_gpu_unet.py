@@ -632,6 +632,21 @@ def test_stock_ddp_wrap_of_the_dropin_module(dev):
         for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
             assert pb.grad is not None and l2_err(pb.grad.cpu(), pa.grad.cpu()) < 1e-3, k
         assert len(wrapped.state_dict()) == 350
+        # the reference trainer's accumulation window (three micro-batches, no_sync on none of them) through the wrapper, on
+        # the module's captured graphs (third pass of the shape on) with their one-launch accumulation: same sums as the bare
+        # module running every kernel from Python
+        ma.train(); mb.train()
+        ma.model.use_graphs = False
+        xs = [(hash_uniform((4, 3, 32, 32), 60 + i) * 2 - 1).to(dev) for i in range(3)]
+        for rep in range(3):
+            ma.zero_grad(set_to_none=True); wrapped.zero_grad(set_to_none=True)
+            for xb in xs:
+                x_t = ma.q(xb, t, noise=noise)
+                crit(ma, t, ma(x_t, t), xb, is_ddp=False)["Loss"].backward()
+                crit(wrapped, t, wrapped(x_t, t), xb, is_ddp=True)["Loss"].backward(retain_graph=True)
+            for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+                assert l2_err(pb.grad.cpu(), pa.grad.cpu()) < 1e-3, (rep, k)
+        assert len(mb.model._graphs) == 1 and next(iter(mb.model._graphs.values())).g_b is not None
     except BaseException as exc:
         import traceback
         traceback.print_exc()
