@@ -1,12 +1,12 @@
-"""Phase timeline of the fused inverted-residual BACKWARD kernel from in-kernel clock stamps (diagnostic build libsirdbg.so:
-hipcc -DSIR_STAMPS ... all csrc/*.hip).  python tools/micro/dbg_sir_bwd.py"""
+"""Phase timeline of the fused inverted-residual BACKWARD kernel from in-kernel clock stamps (diagnostic build tools/micro/lib_sirdbg.so:
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSIR_STAMPS -I diffusion-model_amd/csrc -I include diffusion-model_amd/csrc/*.hip).  python tools/micro/dbg_sir_bwd.py"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import dm_amd_bootstrap  # noqa
 from dm_amd.runtime import hip, ops
-hip.LIB_PATH = os.path.join(ROOT, "tools/micro/libsirdbg.so")
+hip.LIB_PATH = os.path.join(ROOT, "tools/micro/lib_sirdbg.so")
 hip._lib = None
 lib = hip.lib()
 lib.ddpm_sir_bwd_set_dbg.argtypes = [ctypes.c_void_p]
