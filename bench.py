@@ -347,7 +347,7 @@ def main():
                                + (f", self-attention at stages {a.attention_stages}" if a.attention_stages else ""),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph,
                    "grad_exchange": ("none" if not dist else "one all-reduce after backward" if a.no_overlap else
-                                     "2 flat buckets (decoder, encoder), first overlapped with the encoder's backward")},
+                                     "flat ranges of one gradient buffer: decoder half after the 2nd of 4 backward phases, the encoder's deep stages + latent after the 3rd, the small rest at the end; all but the last travel during the backward pass")},
         "final_loss": loss,
     }
 

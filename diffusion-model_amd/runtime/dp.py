@@ -8,9 +8,10 @@ exchange is a single collective on that buffer with no packing pass; averaging i
 where the backend has it.  xGMI rings are per-link bound, so few large messages beat many small ones: `bucket_bytes`
 defaults to one bucket for this network and only splits buffers larger than that.
 
-Overlap: the engine's backward pass runs in two phases (head + decoder, then encoder); runtime/graphs.py's
-OverlappedTrainStep hands the decoder half of the flat buffer to start_range() as soon as phase 0 has produced it, so that
-exchange travels while phase 1 computes; only the encoder half's exchange is exposed.
+Overlap: the engine's backward pass runs in phases (head-first); runtime/graphs.py's OverlappedTrainStep hands a range of
+the flat buffer to start_range() as soon as the phase that completes it is done - the decoder half after the second of four
+phases, the encoder's deep stages and latent layers after the third - so that those exchanges travel while the later phases
+compute; only the exchange of the last phase's few parameters is exposed.
 
 Gradients that are not views of one buffer (a foreign autograd graph, a CPU model under gloo) are gathered into the
 reducer's own flat buffer, reduced there and scattered back."""

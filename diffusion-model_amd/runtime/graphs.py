@@ -178,6 +178,13 @@ class PipelinedTrainStep:
         self.eng.wgrad_tiles_per_split = int(os.environ.get("DDPM_TPS", self.eng.wgrad_tiles_per_split))
         if os.environ.get("DDPM_TPS_PHASES"):
             self.eng.wgrad_tiles_by_phase = [int(v) for v in os.environ["DDPM_TPS_PHASES"].split(",")]
+        # data parallel with the standard four phases (cuts: before encoder stage e, before the decoder's input, before decoder
+        # stage d): the encoder's half of the gradients is exchanged in two parts, see _leaf
+        self._enc_split, self._late_done, self._enc_late, self._enc_rest = None, False, [], []
+        cuts = self.eng._phase_cuts(len(self.eng.spec.stages))
+        enc_cuts = [c for c in cuts if c.startswith("enc") and c[3:].isdigit()]
+        if reducer is not None and len(cuts) == 3 and len(enc_cuts) == 1 and "dec" in cuts and os.environ.get("DDPM_DP_ENC_SPLIT", "1") != "0":
+            self._enc_split = int(enc_cuts[0][3:])
         self.K, self.mid = self.eng.phase_layout()      # mid: the phase after which the decoder half of the gradients is final
         self.loss = torch.zeros(1, device=x0.device)
         self._head_done = torch.zeros(1, device=x0.device, dtype=torch.int32)      # ddpm_train_head's last-workgroup counter
@@ -260,12 +267,22 @@ class PipelinedTrainStep:
         last = p == self.K - 1
         if last:
             self._ctx = None
+        if p == 0:
+            self._late_done = False
         if p == self.mid and self._ready[p]:
             self._ranges[0] = g.unpack_phase("decoder.", 0)
+        if self._enc_split is not None and p == self.K - 2 and self._ready[p] and self._ready[self.mid]:
+            # data parallel: the encoder's deep stages and the latent layers (most of the encoder's bytes) are final one
+            # phase before the end; their exchange travels during the last phase, which leaves a few hundred KB for the end
+            self._enc_late = g.unpack_where("encoder late", self._is_enc_late)
+            self._late_done = True
         if last:
             if not self._ready[self.mid]:               # first pass of a shape: everything becomes final here
                 self._ranges[0] = g.unpack_phase("decoder.", 0)
-            self._ranges[1] = g.unpack_phase("decoder.", 1)
+            if self._late_done:
+                self._enc_rest = g.unpack_where("encoder rest", self._is_enc_rest)
+            else:
+                self._ranges[1] = g.unpack_phase("decoder.", 1)
             if not self._bound:
                 views = g.torch_views()
                 for name, prm in zip(self.unet._param_names, self.unet.parameters()):
@@ -275,6 +292,17 @@ class PipelinedTrainStep:
                 # single GPU: nothing comes between the last gradient and the optimizer, so the update rides at the end
                 # of this graph instead of paying a graph start of its own on the main stream
                 self._adam()
+
+    def _is_enc_late(self, name: str) -> bool:
+        """a parameter of the encoder whose gradient is final after the second-to-last backward phase: encoder stages
+        >= self._enc_split with their time-embedding MLPs, and the latent layers"""
+        for kind in ("encoder.layers.", "encoder.t_embeddings."):
+            if name.startswith(kind):
+                return int(name[len(kind):].split(".", 1)[0]) >= self._enc_split
+        return name.startswith("encoder.latent_layers.")
+
+    def _is_enc_rest(self, name: str) -> bool:
+        return not name.startswith("decoder.") and not self._is_enc_late(name)
 
     @torch.no_grad()
     def _adam(self):
@@ -297,10 +325,15 @@ class PipelinedTrainStep:
         last = p == self.K - 1
         if p == self.mid and self._ready[p]:
             self._handles.append(self.reducer.start_range(flat, *self._ranges[0]))
+        if self._late_done and p == self.K - 2:
+            self._handles += [self.reducer.start_range(flat, lo, hi) for lo, hi in self._enc_late]
         if last:
             if not self._ready[self.mid]:
                 self._handles.append(self.reducer.start_range(flat, *self._ranges[0]))
-            self._handles.append(self.reducer.start_range(flat, *self._ranges[1]))
+            if self._late_done:
+                self._handles += [self.reducer.start_range(flat, lo, hi) for lo, hi in self._enc_rest]
+            else:
+                self._handles.append(self.reducer.start_range(flat, *self._ranges[1]))
 
     def _finish_exchange(self):
         """wait for the started range exchanges in the order they were started (every rank starts them in the same order,

@@ -171,7 +171,7 @@ class GradStore:
         entries = [_entry(fa + 4 * o, fb + 4 * t, S, R, K, Rv, Kv, a_r, a_k, offs, False) for (o, t, S, R, K, Rv, Kv, a_r, a_k, offs) in recipe]
         self._entries, self._names, self._device = entries, list(params.keys()), device
         self._table, self._chunks, self._n = _to_device(entries, device)
-        self._phase_tables: Dict[Tuple[str, int], Tuple[Tensor, Tensor, int, int, int]] = {}
+        self._phase_tables: Dict = {}
 
     def zero(self):
         self.flat.zero_()
@@ -213,6 +213,29 @@ class GradStore:
         tab, chunks, n, lo, hi = self._phase_tables[key]
         hip.call("ddpm_remap", hip.ptr(tab), hip.ptr(chunks), n, 0, hip.stream())
         return lo, hi
+
+    def unpack_where(self, tag: str, keep) -> List[Tuple[int, int]]:
+        """unpack_phase for an arbitrary subset of the parameters (keep(name) -> bool, cached under `tag`): one launch;
+        returns the element ranges [lo, hi) of flat_t the subset occupies, consecutive parameters merged into one range."""
+        if tag not in self._phase_tables:
+            idx = [i for i, n in enumerate(self._names) if keep(n)]
+            if not idx:
+                self._phase_tables[tag] = None
+            else:
+                tab, chunks, n = _to_device([self._entries[i] for i in idx], self._device)
+                ranges, start, prev = [], idx[0], idx[0]
+                for i in idx[1:] + [None]:
+                    if i is None or i != prev + 1:
+                        last = self.tlayout[self._names[prev]]
+                        ranges.append((self.tlayout[self._names[start]][0], last[0] + _ru(_numel(last[1]), 4)))
+                        start = i
+                    prev = i
+                self._phase_tables[tag] = (tab, chunks, n, ranges)
+        t = self._phase_tables[tag]
+        if t is None:
+            return []
+        hip.call("ddpm_remap", hip.ptr(t[0]), hip.ptr(t[1]), t[2], 0, hip.stream())
+        return list(t[3])
 
     def torch_views(self) -> Dict[str, Tensor]:
         """{name: view of the persistent torch-layout staging buffer}: what unpack_phase fills (callers that bind these as

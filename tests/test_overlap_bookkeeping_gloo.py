@@ -15,6 +15,8 @@ from dm_amd.runtime.dp import GradReducer
 from dm_amd.runtime.graphs import OverlappedTrainStep
 
 K, MID, CUT, TOTAL = 4, 1, 40, 100           # phases, the phase that completes the decoder half, the halves' boundary
+LATE = [(8, 24), (28, 40)]                   # the part of the encoder half that is final one phase before the end (two runs)
+REST = [(0, 8), (24, 28)]
 
 
 class _Grads:
@@ -31,6 +33,13 @@ class _Grads:
         self.flat_t[lo:hi] = (torch.arange(lo, hi, dtype=torch.float32) + 1) * (self.rank + 1)
         self.log.append(("unpack", which))
         return lo, hi
+
+    def unpack_where(self, tag, keep):
+        ranges = LATE if tag == "encoder late" else REST
+        for lo, hi in ranges:
+            self.flat_t[lo:hi] = (torch.arange(lo, hi, dtype=torch.float32) + 1) * (self.rank + 1)
+        self.log.append(("unpack", tag))
+        return list(ranges)
 
     def torch_views(self):
         return {"encoder.w": self.flat_t[:CUT], "decoder.w": self.flat_t[CUT:]}
@@ -68,11 +77,12 @@ class _LoggingReducer(GradReducer):
         super().finish(handle[:2])
 
 
-def _drive(rank, ready_at_mid, final):
+def _drive(rank, ready_at_mid, final, enc_split=None):
     """one step of the driver's host logic: per phase the leaf work, then the exchange hook; then the wait"""
     step = object.__new__(OverlappedTrainStep)        # the constructor needs a GPU (streams, capture): wire the host state by hand
     step.eng, step.unet = _Engine(rank, ready_at_mid), _UNet()
     step.K, step.mid = K, MID
+    step._enc_split, step._late_done, step._enc_late, step._enc_rest = enc_split, False, [], []
     step._ctx, step._ranges, step._ready, step._bound, step._handles = object(), [None, None], [False] * K, False, []
     step._sep_adam, step._final = True, final
     log = step.eng.grads.log
@@ -107,6 +117,20 @@ def _worker(rank, world, port, q):
         step, log = _drive(rank, True, False)
         res["accum_log"] = log == [("unpack", 0), ("unpack", 1)]
         res["accum_local"] = torch.equal(step.eng.grads.flat_t, own)
+        # the encoder half in two parts: what is final after the second-to-last phase starts there, the small rest at the end
+        step, log = _drive(rank, True, True, enc_split=1)
+        want = ([("unpack", 0), ("start", CUT, TOTAL), ("unpack", "encoder late")] + [("start",) + r for r in LATE] +
+                [("unpack", "encoder rest")] + [("start",) + r for r in REST] +
+                [("finish", CUT, TOTAL)] + [("finish",) + r for r in LATE] + [("finish",) + r for r in REST])
+        res["split_log"] = log == want
+        res["split_mean"] = torch.allclose(step.eng.grads.flat_t, mean)
+        # first pass of a shape with the split on: nothing is final early, the whole encoder half goes out at the end
+        step, log = _drive(rank, False, True, enc_split=1)
+        res["split_first_log"] = log == [("unpack", 0), ("unpack", 1), ("start", CUT, TOTAL), ("start", 0, CUT),
+                                         ("finish", CUT, TOTAL), ("finish", 0, CUT)]
+        res["split_first_mean"] = torch.allclose(step.eng.grads.flat_t, mean)
+        step, log = _drive(rank, True, False, enc_split=1)
+        res["split_accum_log"] = log == [("unpack", 0), ("unpack", "encoder late"), ("unpack", "encoder rest")]
         q.put((rank, res))
     finally:
         td.destroy_process_group()
