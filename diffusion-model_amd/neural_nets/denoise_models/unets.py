@@ -10,6 +10,7 @@ runtime/engine.py, entered through one autograd Function.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Callable, Dict, List, Tuple
 
 import torch
@@ -175,7 +176,8 @@ class _GraphEntry:
         self.keep = [eng._zero_arena, eng.grads.flat if eng.grads is not None else None, eng.grads.flat_t if eng.grads is not None else None]
 
     def __del__(self):
-        _RETIRED_GRAPHS.append((getattr(self, "g_f", None), getattr(self, "g_b", None)))
+        if _RETIRED_GRAPHS is not None:                 # (None while the interpreter shuts down)
+            _RETIRED_GRAPHS.append((getattr(self, "g_f", None), getattr(self, "g_b", None)))
 
     def usable(self) -> bool:
         """not while an earlier call's autograd graph may still run its backward on the static buffers"""
@@ -187,7 +189,6 @@ class _GraphEntry:
         self.g_f.replay()
         tok = None
         if self.record:
-            import weakref
             tok = _Token()
             self.live, self.pending = weakref.ref(tok), True
         return self.out.clone(), tok
