@@ -52,3 +52,7 @@ for r in main[:34]:
 print("main queue, first and last kernels:")
 for r in main[:10] + main[-8:]:
     print(f"   {(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:8.1f}  {r['Kernel_Name'][:70]}  grid {r.get('Grid_Size', r.get('Grid_Size_X', ''))}")
+if len(sys.argv) > 2:            # second argument: file for the whole main-queue sequence
+    with open(sys.argv[2], "w") as f:
+        for r in main:
+            f.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f}  {r['Kernel_Name'][:90]}\n")
