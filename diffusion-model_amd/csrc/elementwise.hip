@@ -229,6 +229,73 @@ extern "C" int ddpm_elbo_bwd(const float* pred, const float* target, const int64
     return ddpm_check_launch("elbo_bwd");
 }
 
+// The squared-error ELBO of a tanh-headed denoiser and everything between it and the last convolution's weight / data
+// gradients in one launch: loss (as elbo_fwd_kernel), dL/dpred (as elbo_bwd_kernel with no upstream scale), the tanh
+// backward into the channel-padded NHWC bf16 gradient of the logits (as tanh_bwd_kernel) and that gradient's per-channel sum,
+// the bias gradient of the last convolution (as colsum_kernel over the bf16 values).  Four dependent launches on a 1 MB
+// tensor otherwise; same arithmetic and rounding points, so dz is bit-identical to the separate kernels' (the two sums are
+// added in another order).  A thread owns one pixel with all its channels.
+__global__ __launch_bounds__(256) void elbo_tanh_head_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                              const long long* __restrict__ t, const float* __restrict__ sched,
+                                                              float* __restrict__ loss, bf16* __restrict__ dz, float* __restrict__ bias_grad,
+                                                              int N, int C, int HW, int weighted) {
+    __shared__ float part[4][17];
+    const long long total = (long long)N * HW;
+    const long long chw = (long long)C * HW;
+    const float inv = 1.0f / (float)((double)N * (double)chw);
+    float acc = 0.f, bs[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bs[c] = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW);
+        const int p = (int)(i - (long long)n * HW);
+        const float wt = weighted ? sched[(int)t[n] * SC_STRIDE + SC_W] : 1.0f;
+        const float w = wt * inv;
+        bf16x8 lo, hi;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            bf16 o = (bf16)0.f;
+            if (c < C) {
+                const long long e = ((long long)n * C + c) * HW + p;
+                const float yy = pred[e], d = yy - target[e];
+                s += d * d;
+                const float g = w * (2.0f * d);
+                o = (bf16)(g * (1.0f - yy * yy));
+                bs[c] += (float)o;
+            }
+            if (c < 8) lo[c & 7] = o; else hi[c & 7] = o;
+        }
+        acc += wt * s;
+        *(bf16x8*)(dz + i * 16) = lo;
+        *(bf16x8*)(dz + i * 16 + 8) = hi;
+    }
+    const int wave = threadIdx.x >> 6;
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[wave][16] = acc;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < C) {
+            const float v = wave_sum(bs[c]);
+            if ((threadIdx.x & 63) == 0) part[wave][c] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0][16] + part[1][16] + part[2][16] + part[3][16]) * inv);
+    if (threadIdx.x < C) atomicAdd(bias_grad + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+extern "C" int ddpm_elbo_tanh_head(const float* pred, const float* target, const int64_t* t_, const float* sched, float* loss, void* dz,
+                                   float* bias_grad, int N, int C, int HW, int weighted, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(pred && target && t_ && sched && loss && dz && bias_grad, "elbo_tanh_head: null pointer");
+    DDPM_REQUIRE(N > 0 && C > 0 && C <= 16 && HW > 0, "elbo_tanh_head: 1..16 image channels (got %d)", C);
+    if (hipMemsetAsync(loss, 0, sizeof(float), stream) != hipSuccess) return ddpm_check_launch("elbo_tanh_head memset");
+    hipLaunchKernelGGL(elbo_tanh_head_kernel, dim3(stream_grid((long long)N * HW, 256)), dim3(256), 0, stream, pred, target,
+                       (const long long*)t_, sched, loss, (bf16*)dz, bias_grad, N, C, HW, weighted);
+    return ddpm_check_launch("elbo_tanh_head");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sinusoidal time embedding (reference constituent_blocks.py:261-279; time normalised as in
 // unets.py:121): out[n] = [sin(t/Tn * f_i), cos(t/Tn * f_i)], f_i = exp(-i ln(1e4)/(half-1)).

@@ -900,12 +900,19 @@ class UNetEngine:
         out = ops.conv_forward(K33, hfeat.v, wc.fwd[name], bias, c_img, act=hip.ACT["tanh"], f32_nchw=True)
         if tape is not None:
             out_holder = Var(out)
+            head_dz: List[Optional[Tensor]] = [None]
+            self._head_slot = (head_dz, G[name + ".bias"], (n, h, w, cpad, c_img))
 
             def bwd_head():
-                dz = torch.empty(n, h, w, cpad, device=dev, dtype=BF16)
-                dy = out_holder.g.contiguous()
-                hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, cpad, hip.stream())
-                ops.colsum(dz, G[name + ".bias"], c_img)
+                if head_dz[0] is not None:
+                    # a caller that fused the loss with the head's gradient (ddpm_elbo_tanh_head) brings the gradient of the
+                    # logits and has added the bias gradient already
+                    dz, head_dz[0] = head_dz[0], None
+                else:
+                    dz = torch.empty(n, h, w, cpad, device=dev, dtype=BF16)
+                    dy = out_holder.g.contiguous()
+                    hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dy), hip.ptr(out), hip.ptr(dz), n, c_img, h * w, cpad, hip.stream())
+                    ops.colsum(dz, G[name + ".bias"], c_img)
                 wgrad(K33, hfeat.v, dz, c_img, name)
                 hfeat.g = ops.conv_forward(K33, dz, wc.dgrad[name], None, hfeat.v.shape[3], c0_used=c_img if c_img <= 4 else 0)
             tape.append(bwd_head)
@@ -1019,8 +1026,29 @@ class UNetEngine:
             return None
         return self.grads.unpack()
 
-    def backward_data(self, ctx, phase: int, dout: Optional[Tensor] = None) -> None:
-        """The data-gradient chain of one backward phase (phase 0 starts from dout = gradient of the network output).
+    def backward_begin(self) -> None:
+        """What opens a backward pass: the gradient sums and the pass's zeroed accumulators are cleared.  backward_data(phase 0)
+        does it by itself unless told that the caller already has (begun=True)."""
+        if not self.external_zero:
+            self.grads.zero()
+        if self._zero_arena is not None:
+            self._zero_arena.zero_()
+        self._zero_cursor = self._zero_need = 0
+
+    def head_gradient_slot(self):
+        """For a caller that computes the loss and the gradient of the last convolution's logits itself, after
+        backward_begin() and before backward_data(ctx, 0, None, begun=True): (setter for the channel-padded NHWC bf16
+        gradient of the logits, the fp32 bias gradient of the last convolution to add the gradient's per-channel sums to,
+        (N, H, W, padded channels, image channels)) of the forward pass recorded last."""
+        holder, bias_grad, dims = self._head_slot
+
+        def put(dz: Tensor) -> None:
+            holder[0] = dz
+        return put, bias_grad, dims
+
+    def backward_data(self, ctx, phase: int, dout: Optional[Tensor] = None, begun: bool = False) -> None:
+        """The data-gradient chain of one backward phase (phase 0 starts from dout = gradient of the network output, or from
+        the gradient of the logits handed over through head_gradient_slot()).
         Phases run head-first: with 2 phases, 0 = head + decoder and 1 = encoder; with 4, each of those is halved at its
         middle stage.  Leaf work (weight gradients, partial-sum folds, time-embedding MLPs) is only queued here."""
         tape, out_holder, _, marks = ctx
@@ -1028,11 +1056,8 @@ class UNetEngine:
         if self.wgrad_tiles_by_phase:
             self._cur_tps = self.wgrad_tiles_by_phase[min(phase, len(self.wgrad_tiles_by_phase) - 1)]
         if phase == 0:
-            if not self.external_zero:
-                self.grads.zero()
-            if self._zero_arena is not None:
-                self._zero_arena.zero_()
-            self._zero_cursor = self._zero_need = 0
+            if not begun:
+                self.backward_begin()
             out_holder.g = dout
         bounds = [0] + list(marks) + [len(tape)]
         seg = len(bounds) - 2 - phase

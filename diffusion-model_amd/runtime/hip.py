@@ -114,6 +114,7 @@ _PROTOS = {
     "ddpm_fill_normal": ([_vp, _i64, _vp, _u32, C.c_uint64, _vp], _i),
     "ddpm_elbo_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
     "ddpm_elbo_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp], _i),
+    "ddpm_elbo_tanh_head": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_time_embedding": ([_vp, _f, _i, _vp, _i, _vp], _i),
     "ddpm_nchw_f32_to_nhwc_bf16": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_nhwc_bf16_to_nchw_f32": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),

@@ -80,6 +80,12 @@ int ddpm_elbo_fwd(const float* pred, const float* target, const int64_t* t, cons
 /* its gradient w.r.t. pred, times the upstream scalar *gscale (NULL = 1). */
 int ddpm_elbo_bwd(const float* pred, const float* target, const int64_t* t, const float* sched, const float* gscale,
                   float* gpred, int N, int64_t chw, int bce, int weighted, ddpm_stream_t stream);
+/* The squared-error ELBO of a tanh-headed denoiser (losses/ELBO.py:61-76 with reconstruction_method "mse", the Tanh of
+ * unets.py:183 there) and the gradient chain down to the last convolution in one launch: *loss as ddpm_elbo_fwd, dz = the
+ * channel-padded (16) NHWC bf16 gradient of the logits as ddpm_elbo_bwd + ddpm_tanh_bwd_nchw_to_nhwc give it (bit-identical),
+ * bias_grad[c] += its per-channel sum as ddpm_colsum gives it.  pred = the network's output (after the tanh), NCHW fp32. */
+int ddpm_elbo_tanh_head(const float* pred, const float* target, const int64_t* t, const float* sched, float* loss, void* dz,
+                        float* bias_grad, int N, int C, int HW, int weighted, ddpm_stream_t stream);
 
 /* SinusoidalPositionEmbedBlock.forward on t / time_norm (constituent_blocks.py:261-279; unets.py:121,233).
  * out: bf16 [N][dim]. */

@@ -201,3 +201,32 @@ def test_timestep_range_check_does_not_stall_and_raises(dev):
     m.reverse_q(x, x, torch.tensor([0, 3, 4], device=dev), noise=noise)     # the reverse step starts at t = 1
     with pytest.raises(IndexError):
         m.check_timesteps(wait=True)
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_fused_loss_and_head_gradient_matches_the_separate_kernels(dev, c):
+    """ddpm_elbo_tanh_head = ddpm_elbo_fwd + ddpm_elbo_bwd + ddpm_tanh_bwd_nchw_to_nhwc + ddpm_colsum in one launch: the
+    gradient of the logits bit for bit, the two sums (loss, bias gradient) to fp32 rounding of their order."""
+    from dm_amd.runtime import hip, ops
+    n, hw = 37, 32 * 32
+    y = torch.tanh(hash_normal((n, c, 32, 32), 71)).to(dev)
+    x0 = (hash_uniform((n, c, 32, 32), 72) * 2 - 1).to(dev)
+    t = torch.randint(1, 121, (n,), device=dev)
+    table = (torch.rand(121, 8, device=dev) + 0.5).contiguous()
+    for weighted in (1, 0):
+        loss_a, loss_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        hip.call("ddpm_elbo_fwd", hip.ptr(y), hip.ptr(x0), hip.ptr(t), hip.ptr(table), hip.ptr(loss_a), n, c * hw, 0, weighted, hip.stream())
+        dpred = torch.empty_like(y)
+        hip.call("ddpm_elbo_bwd", hip.ptr(y), hip.ptr(x0), hip.ptr(t), hip.ptr(table), None, hip.ptr(dpred), n, c * hw, 0, weighted, hip.stream())
+        dz_a = torch.empty(n, 32, 32, 16, device=dev, dtype=torch.bfloat16)
+        hip.call("ddpm_tanh_bwd_nchw_to_nhwc", hip.ptr(dpred), hip.ptr(y), hip.ptr(dz_a), n, c, hw, 16, hip.stream())
+        bias_a = torch.full((c,), 0.25, device=dev)
+        ops.colsum(dz_a, bias_a, c)
+        dz_b = torch.full((n, 32, 32, 16), float("nan"), device=dev, dtype=torch.bfloat16)
+        bias_b = torch.full((c,), 0.25, device=dev)
+        hip.call("ddpm_elbo_tanh_head", hip.ptr(y), hip.ptr(x0), hip.ptr(t), hip.ptr(table), hip.ptr(loss_b), hip.ptr(dz_b), hip.ptr(bias_b),
+                 n, c, hw, weighted, hip.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dz_a.view(torch.int16), dz_b.view(torch.int16))
+        assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
+        torch.testing.assert_close(bias_b, bias_a, rtol=1e-4, atol=1e-7)
