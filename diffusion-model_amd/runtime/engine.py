@@ -168,7 +168,7 @@ class UNetEngine:
         self._mask_seed = None
         self.fuse_embed = True          # all time-embedding MLPs in one forward and one backward launch
         self.wgrad_tiles_per_split = 8  # grouped weight gradients: 128-position tiles per position split
-        self.wgrad_tiles_last = 2       # the same for the last phase of a multi-phase backward, whose group launch runs alone
+        self.wgrad_tiles_last = 4       # the same for the last phase of a multi-phase backward, whose group launch runs alone
         self.wgrad_tiles_by_phase = None
         self._cur_tps = 8
         self.group_wgrad = True         # defer the dense weight gradients to the end of backward and launch them together

@@ -137,7 +137,7 @@ class PipelinedTrainStep:
     they run inside the start-up latency of the next step's first graph.
 
     (4 phases measured best: with one phase per stage the leaf launches become too small to keep the side stream ahead.
-    The last phase's leaf work runs alone, so its weight-gradient problems are cut into more, shorter position splits.)
+    The last phase's leaf work runs alone, so its weight-gradient problems are cut into more, shorter position splits (4 instead of 8 tiles each).)
 
     Data parallel (reducer given): the reference's DDP wrapper overlaps bucketed all-reduces with autograd's backward
     (base_trainer.py:95-100 there).  Here the `decoder.*` half of the flat gradient buffer is final after the middle
