@@ -32,6 +32,9 @@ struct ConvArgs {
     float* sum_out;                  // optional fp32 [N][Cout] per-image sums of the activated output (atomics)
     bf16* out2; int act2;            // optional second result act2(out), same layout: a unit without normalisation keeps its
                                      // pre-activation for the backward pass and hands the activated tensor on
+    float* gn_part; int gn_G, gn_PT; // optional (STATS kernels): per (image, group, output tile) sums of the rounded result and of
+                                     // its squares, fp32 [N][gn_G][gn_PT][2]: what the GroupNorm that follows needs, without a
+                                     // statistics pass over the tensor
 };
 
 // Loads are issued in batches of STAGE_U per thread before any of them is consumed, so that each thread keeps
@@ -54,7 +57,7 @@ extern "C" int ddpm_conv_set_dbg(unsigned long long* p) {
 #define CONV_STAMP(i)
 #endif
 
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, bool STATS = false>
 __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int T = 256, BM = 32 * WM, BNW = 32 * NT, BN = BNW * WN;
     constexpr int OS = BN * 2 + 16;   // epilogue LDS row stride (bytes)
@@ -290,6 +293,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
     __syncthreads();
     CONV_STAMP(6);
     bf16* out = (bf16*)a.out;
+    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_ss[4] = {0.f, 0.f, 0.f, 0.f};   // STATS: sums of this thread's four channel pairs (its
+                                                                            // 8-channel column is the same for all its rows)
     for (int it = tid; it < BM * (BN / 8); it += T) {
         const int row = it / (BN / 8), part = it - row * (BN / 8);
         const int co = co0 + part * 8;
@@ -301,6 +306,10 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
         if (!(n < g.N && py < g.GH && px < g.GW && oh < g.OH && ow < g.OW)) continue;
         const long long e = ((long long)(n * g.OH + oh) * g.OW + ow) * a.out_cs + co;
         bf16x8 v = *(const bf16x8*)(s_out + row * OS + part * 16);
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+        }
         if (a.out_mask) {
             const unsigned m = a.out_mask[e >> 3];
 #pragma unroll
@@ -331,14 +340,44 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
             *(bf16x8*)(a.out2 + e) = y;
         }
     }
+    if constexpr (STATS) {
+        // Every tile lies in one image and holds whole groups of 2, 4, 8, ... channels (host-checked).  Lanes that share a
+        // column add up by shuffles, the four waves' column sums meet in LDS, and one thread per group adds its channel pairs
+        // in a fixed order (deterministic) and stores the tile's pair.
+        constexpr int PARTS = BN / 8;
+#pragma unroll
+        for (int o = PARTS; o < 64; o <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { st_s[q] += __shfl_xor(st_s[q], o); st_ss[q] += __shfl_xor(st_ss[q], o); }
+        }
+        __syncthreads();                               // the output tile in LDS has been read by everyone
+        float* red = (float*)smem;                     // [wave][column][4 sums, 4 sums of squares]
+        if (lane < PARTS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { red[((tid >> 6) * PARTS + lane) * 8 + q] = st_s[q]; red[((tid >> 6) * PARTS + lane) * 8 + 4 + q] = st_ss[q]; }
+        }
+        __syncthreads();
+        const int cpg = a.Cout / a.gn_G;
+        if (tid < BN / cpg) {
+            float S = 0.f, SS = 0.f;
+            for (int c2 = tid * cpg / 2; c2 < (tid + 1) * cpg / 2; ++c2) {
+                const int col = c2 >> 2, q = c2 & 3;
+#pragma unroll
+                for (int w = 0; w < T / 64; ++w) { S += red[(w * PARTS + col) * 8 + q]; SS += red[(w * PARTS + col) * 8 + 4 + q]; }
+            }
+            const int tile_in_image = (cls * g.tiles_h + thi) * g.tiles_w + twi;
+            float* o = a.gn_part + (((long long)n0 * a.gn_G + co0 / cpg + tid) * a.gn_PT + tile_in_image) * 2;
+            o[0] = S; o[1] = SS;
+        }
+    }
     CONV_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, bool STATS = false>
 static int launch_conv(const ConvArgs& a, size_t lds, hipStream_t stream) {
     const ConvGeom& g = a.g;
-    auto k = conv_mfma_kernel<WM, WN, NT>;
+    auto k = conv_mfma_kernel<WM, WN, NT, STATS>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ddpm_check_launch("conv: raise dynamic LDS limit");
@@ -358,6 +397,9 @@ extern "C" int ddpm_conv_debug_tile(int force) {
     return last;
 }
 
+static int conv_general(const ddpm_conv_desc* d, hipStream_t stream);
+extern "C" int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d);
+
 extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DDPM_REQUIRE(d && d->in0 && d->w && d->out, "conv: null pointer");
@@ -372,6 +414,12 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
+    if (d->gn_part) {
+        // per-tile GroupNorm sums come from the general kernel's epilogue only (large images, where the GroupNorm that follows
+        // takes its many-workgroup path): the caller has asked ddpm_conv_gn_part_tiles first
+        DDPM_REQUIRE(ddpm_conv_gn_part_tiles(d) > 0, "conv: no per-tile GroupNorm sums for this problem (ask ddpm_conv_gn_part_tiles first)");
+        return conv_general(d, stream);
+    }
     // 3x3 convolutions on 2x2 / 4x4 images (the deepest stages) have their own kernel
     if (const int rc = ddpm_conv_small_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_SMALL; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     // whole-image tiles: the unit's GroupNorm (forward) or its backward (data-gradient launches) runs in the same launch
@@ -380,37 +428,69 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     // the image head (a handful of output channels) runs on the vector ALUs
     if (const int rc = ddpm_conv_thin_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_THIN; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     DDPM_REQUIRE(!d->gn_gamma, "conv: no fused GroupNorm for this shape (ask ddpm_conv_gn_fusable first)");
+    return conv_general(d, stream);
+}
 
-    ConvArgs a;
-    // Tile choice.  Workgroup = 4 waves as WM x WN; tile = (32*WM) positions x (32*NT*WN) output channels.
-    // Start from the largest tile (most operand reuse) and shrink it until the launch has >= 384 workgroups
-    // (1.5 per CU) or cannot shrink further: these layers are latency/bandwidth bound, so parallelism wins.
+struct ConvCfg { int wm, wn, nt; };
+
+// Tile of the general kernel for a problem (and its geometry in *g): -1 when none fits.
+static int conv_pick(const ddpm_conv_desc* d, ConvCfg* out, ConvGeom* g) {
     const int kind_taps = (d->kind == CONV_3X3_S1 || d->kind == CONV_3X3_S2) ? 9 : 4;
     const int co32 = d->CoutW / 32;
-    struct Cfg { int wm, wn, nt; };
-    const Cfg cands[] = {{4, 1, 4}, {4, 1, 2}, {2, 2, 2}, {4, 1, 1}, {2, 2, 1}};
+    const ConvCfg cands[] = {{4, 1, 4}, {4, 1, 2}, {2, 2, 2}, {4, 1, 1}, {2, 2, 1}};
     int pick = -1;
     for (int i = 0; i < 5; ++i) {
-        const Cfg c = cands[i];
+        const ConvCfg c = cands[i];
         const int bn32 = c.nt * c.wn;
         if (co32 % bn32) continue;
         if (kind_taps >= 9 && bn32 > 2) continue;                 // 9 taps x 128 rows of weights would not fit LDS comfortably
-        if (conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 32 * c.wm) != 0) { ddpm_set_error("conv: geometry"); return DDPM_EINVAL; }
-        const long long blocks = (long long)a.g.tiles_n * a.g.tiles_h * a.g.tiles_w * (co32 / bn32) * a.g.ncls;
+        if (conv_geom_init(g, d->kind, d->N, d->IH, d->IW, 32 * c.wm) != 0) return -2;
+        const long long blocks = (long long)g->tiles_n * g->tiles_h * g->tiles_w * (co32 / bn32) * g->ncls;
         pick = i;
         if (g_force_tile ? g_force_tile == c.wm * 100 + c.wn * 10 + c.nt : blocks >= 384) break;
         if (g_force_tile) pick = -1;
     }
+    if (pick < 0) return -1;
+    *out = cands[pick];
+    conv_geom_init(g, d->kind, d->N, d->IH, d->IW, 32 * out->wm);
+    return pick;
+}
+
+// Partial-sum slots per (image, group) that a launch with gn_part writes (0: this problem cannot deliver them): the general
+// kernel's tiles must each lie inside one image, cover only valid positions and hold whole groups of 2, 4, 8, ... channels.
+extern "C" int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d) {
+    if (!d || d->gn_part_groups <= 0) return 0;
+    if (d->kind != CONV_3X3_S1 && d->kind != CONV_1X1 && d->kind != CONVT_2X2_S2) return 0;
+    if (d->out_mode != OUT_BF16_NHWC || d->out_mask || d->res || d->act != 0 || d->Cout != d->CoutW || d->Cout % d->gn_part_groups) return 0;
+    if (d->gn_gamma || d->gnb_raw || d->out2 || d->sum_out || d->C0_used) return 0;
+    if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->CoutW <= 0 || d->CoutW % 32) return 0;
+    const int cpg = d->Cout / d->gn_part_groups;
+    if (cpg < 2 || (cpg & (cpg - 1))) return 0;
+    ConvCfg cfg; ConvGeom g;
+    if (conv_pick(d, &cfg, &g) < 0) return 0;
+    const int bn = 32 * cfg.nt * cfg.wn;
+    if (bn % cpg || g.NB != 1 || g.GH % g.TH || g.GW % g.TW) return 0;
+    if ((long long)g.OH * g.OW < 4096) return 0;       // smaller images: whole-image kernels / a cheap statistics pass
+    return g.ncls * g.tiles_h * g.tiles_w;
+}
+
+static int conv_general(const ddpm_conv_desc* d, hipStream_t stream) {
+    ConvArgs a;
+    // Tile choice.  Workgroup = 4 waves as WM x WN; tile = (32*WM) positions x (32*NT*WN) output channels.
+    // Start from the largest tile (most operand reuse) and shrink it until the launch has >= 384 workgroups
+    // (1.5 per CU) or cannot shrink further: these layers are latency/bandwidth bound, so parallelism wins.
+    ConvCfg cfg;
+    const int pick = conv_pick(d, &cfg, &a.g);
+    DDPM_REQUIRE(pick != -2, "conv: geometry");
     DDPM_REQUIRE(pick >= 0 || !g_force_tile, "conv: forced tile %d is not available for CoutW=%d, kind %d", g_force_tile, d->CoutW, d->kind);
     DDPM_REQUIRE(pick >= 0, "conv: no tile configuration for CoutW=%d", d->CoutW);
-    const Cfg cfg = cands[pick];
-    conv_geom_init(&a.g, d->kind, d->N, d->IH, d->IW, 32 * cfg.wm);
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1;
     a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = d->out; a.res = (const bf16*)d->res;
     a.out_mask = d->out_mask; a.out_mask_scale = d->out_mask_scale;
     a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.out_mode = d->out_mode; a.sum_out = d->sum_out;
     a.out2 = (bf16*)d->out2; a.act2 = d->act2;
+    a.gn_part = d->gn_part; a.gn_G = d->gn_part_groups; a.gn_PT = a.g.ncls * a.g.tiles_h * a.g.tiles_w;
     DDPM_REQUIRE(!d->out2 || (d->out_mode == OUT_BF16_NHWC && d->Cout % 8 == 0 && d->act == 0), "conv: the second (activated) result needs an NHWC bf16 output, Cout %% 8 == 0 and no first activation");
     DDPM_REQUIRE(!ACT_HAS_BETA(d->act) && !ACT_HAS_BETA(d->act2) && !ACT_HAS_BETA(d->gn_act) && !ACT_HAS_BETA(d->gnb_act),
                  "conv: swish / hardswish (learnable scalar) are not fused into the convolution launches; apply them with ddpm_gn_act_forward / _backward");
@@ -424,6 +504,12 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
     if (lds < lds_out) lds = lds_out;
     DDPM_REQUIRE(lds <= 160 * 1024, "conv: tile needs %zu B of LDS", lds);
 
+    if (a.gn_part) {
+        if (lds < 4 * 16 * 8 * sizeof(float)) lds = 4 * 16 * 8 * sizeof(float);
+#define CONV_CASE(WMv, WNv, NTv) if (cfg.wm == WMv && cfg.wn == WNv && cfg.nt == NTv) return launch_conv<WMv, WNv, NTv, true>(a, lds, stream);
+        CONV_CASE(4, 1, 4) CONV_CASE(4, 1, 2) CONV_CASE(2, 2, 2) CONV_CASE(4, 1, 1) CONV_CASE(2, 2, 1)
+#undef CONV_CASE
+    }
 #define CONV_CASE(WMv, WNv, NTv) if (cfg.wm == WMv && cfg.wn == WNv && cfg.nt == NTv) return launch_conv<WMv, WNv, NTv>(a, lds, stream);
     CONV_CASE(4, 1, 4) CONV_CASE(4, 1, 2) CONV_CASE(2, 2, 2) CONV_CASE(4, 1, 1) CONV_CASE(2, 2, 1)
 #undef CONV_CASE

@@ -33,7 +33,7 @@ int ddpm_check_launch(const char* what) {
 }
 
 extern "C" const char* ddpm_last_error(void) { return g_err; }
-extern "C" int ddpm_abi_version(void) { return 2; }
+extern "C" int ddpm_abi_version(void) { return 3; }
 
 static inline int stream_grid(long long work_items, int block) {
     long long g = (work_items + block - 1) / block;

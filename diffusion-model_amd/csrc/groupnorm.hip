@@ -41,6 +41,7 @@ struct GnArgs {
     float* part;                   // [N][3][C] fp32 per-image partial sums: dgamma, dbeta, sum of dx (= the producing conv's
                                    // bias gradient); every element is written exactly once, a later pass sums over N
     int N, HW, C, G, SC;           // SC = slab width (channels)
+    const float* sp; int NP;       // split forward, optional: [N][G][NP][2] partial sums the producing convolution stored
     int act;
     float eps;
     const float* act_beta;         // the activation's learnable scalar (swish / hardswish), else unused
@@ -424,7 +425,33 @@ __device__ __forceinline__ void gn_fwd_split_apply_body(const GnArgs& a) {
     const int cpg = a.G > 0 ? a.C / a.G : 1;
     if (a.G > 0) {
         const int ngrp = a.SC / cpg;
-        if (tid < ngrp && a.fixed) {
+        if (a.sp) {
+            // the producing convolution left NP partial pairs per (image, group).  A slab holds 1, 2, 4, ... 32 groups: the
+            // workgroup's threads share them out, and each group's threads fold their sums in a fixed order (deterministic)
+            __shared__ float s_fs[32], s_fss[32];
+            const int tpg = GS_T / ngrp;                                  // 8 .. 256 threads per group
+            const int gi = tid / tpg, k = tid - gi * tpg;
+            const float2* in = (const float2*)a.sp + ((long long)n * a.G + c0 / cpg + gi) * a.NP;
+            float S = 0.f, SS = 0.f;
+            for (int q = k; q < a.NP; q += tpg) { const float2 v = in[q]; S += v.x; SS += v.y; }
+            for (int o = 1; o < 64 && o < tpg; o <<= 1) { S += __shfl_xor(S, o); SS += __shfl_xor(SS, o); }
+            const int lpg = tpg < 64 ? tpg : 64;                          // lanes behind each of the sums that are left
+            if (tid % lpg == 0) { s_fs[tid / lpg] = S; s_fss[tid / lpg] = SS; }
+            __syncthreads();
+            if (tid < ngrp) {
+                const int per = tpg / lpg, g = c0 / cpg + tid;
+                S = SS = 0.f;
+                for (int i = 0; i < per; ++i) { S += s_fs[tid * per + i]; SS += s_fss[tid * per + i]; }
+                const float m = 1.0f / (float)(cpg * a.HW);
+                const float mean = S * m;
+                const float rstd = rsqrtf(fmaxf(SS * m - mean * mean, 0.f) + a.eps);
+                s_mean[tid] = mean; s_rstd[tid] = rstd;
+                if (p == 0 && a.stats) {
+                    a.stats[((long long)n * a.G + g) * 2 + 0] = mean;
+                    a.stats[((long long)n * a.G + g) * 2 + 1] = rstd;
+                }
+            }
+        } else if (tid < ngrp && a.fixed) {
             const int g = c0 / cpg + tid;
             s_mean[tid] = a.stats[((long long)n * a.G + g) * 2 + 0];
             s_rstd[tid] = a.stats[((long long)n * a.G + g) * 2 + 1];
@@ -682,6 +709,7 @@ static int gn_prepare(GnArgs& a, const ddpm_gn_desc* d, const char* what) {
     DDPM_REQUIRE(!ACT_HAS_BETA(d->act) || d->act_beta, "%s: swish / hardswish need their scalar (act_beta)", what);
     a.act_beta = d->act_beta; a.dbeta_part = d->dbeta_part;
     a.scratch = d->scratch; a.P = 0; a.rows_per_split = 0;
+    a.sp = nullptr; a.NP = 0;
     a.fixed = d->fixed_stats != 0;
     DDPM_REQUIRE(!a.fixed || (d->G > 0 && d->stats), "%s: fixed_stats needs groups and the stats tensor", what);
     return DDPM_OK;
@@ -736,7 +764,11 @@ extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_)
     if (int rc = gn_prepare(a, d, "gn_forward")) return rc;
     if (gn_use_split(a, d, false)) {
         const int units = a.N * (a.C / a.SC) * a.P;
-        if (a.G > 0 && !a.fixed) hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        if (d->stat_part && d->stat_parts > 0 && a.G > 0 && !a.fixed && GS_T % (a.SC / (a.C / a.G)) == 0) {
+            a.sp = d->stat_part; a.NP = d->stat_parts;        // the producing convolution has summed already
+        } else if (a.G > 0 && !a.fixed) {
+            hipLaunchKernelGGL(gn_fwd_split_stats_kernel, dim3(units), dim3(GS_T), 0, stream, a);
+        }
         hipLaunchKernelGGL(gn_fwd_split_apply_kernel, dim3(units), dim3(GS_T), 0, stream, a);
         return ddpm_check_launch("gn_forward");
     }

@@ -177,6 +177,7 @@ class UNetEngine:
         self._pin_spares: List[Tensor] = []           # handed one by one to graph captures, which then own them for good
         self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
+        self.conv_stats = os.environ.get("DDPM_CONV_STATS", "1") != "0"   # large images: GroupNorm sums from the convolution's tiles
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
         self.phases = 1                 # backward in 1, 2 (decoder | encoder), 4 (each halved at its middle stage), 5 (the last
                                         # of those cut again after the first encoder convolution) or, for any larger value,
@@ -404,10 +405,14 @@ class UNetEngine:
                                           c0_used=c0_used)
                 stats = None
             else:
+                # large images: the convolution's tiles leave their sums for the normalisation (no statistics pass)
+                want = groups if (norm and self.conv_stats and not c0_used) else 0
                 raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
-                                       in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, c0_used=c0_used)
+                                       in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, c0_used=c0_used,
+                                       gn_part_groups=want)
+                raw, spart = raw if want else (raw, None)
                 y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
-                                              mask=out_mask, mask_scale=mscale, act_beta=bsc)
+                                              mask=out_mask, mask_scale=mscale, act_beta=bsc, stat_part=spart)
             out = Var(y)
             if tape is not None:
                 tape.append(conv_bwd(name, x0, x1, in_add, in_mask, raw, out, stats, norm, groups, act, res, out_mask))

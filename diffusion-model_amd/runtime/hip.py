@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_stats", _vp), ("gn_res", _vp),
         ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("out2", _vp), ("act2", _i),
         ("gnb_raw", _vp), ("gnb_gamma", _vp), ("gnb_beta", _vp), ("gnb_stats", _vp), ("gnb_part", _vp), ("gnb_draw", _vp),
-        ("gnb_groups", _i), ("gnb_act", _i), ("C0_used", _i),
+        ("gnb_groups", _i), ("gnb_act", _i), ("C0_used", _i), ("gn_part", _vp), ("gn_part_groups", _i),
     ]
 
 
@@ -44,7 +44,7 @@ class GnDesc(C.Structure):
         ("x", _vp), ("gamma", _vp), ("beta", _vp), ("res", _vp), ("mask", _vp), ("mask_scale", _f),
         ("y", _vp), ("stats", _vp), ("dy", _vp), ("part", _vp),
         ("N", _i), ("HW", _i), ("C", _i), ("G", _i), ("act", _i), ("eps", _f), ("scratch", _vp), ("scratch_floats", _i64),
-        ("act_beta", _vp), ("dbeta_part", _vp), ("fixed_stats", _i),
+        ("act_beta", _vp), ("dbeta_part", _vp), ("fixed_stats", _i), ("stat_part", _vp), ("stat_parts", _i),
     ]
 
 
@@ -128,6 +128,7 @@ _PROTOS = {
     "ddpm_conv_debug_tile": ([_i], _i),
     "ddpm_conv_last_kernel": ([], _i),
     "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),
+    "ddpm_conv_gn_part_tiles": ([C.POINTER(ConvDesc)], _i),
     "ddpm_conv_gnb_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),

@@ -49,7 +49,8 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                  in_add: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, in_scale: float = 1.0, act: int = 0,
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
                  out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
-                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None, gnb=None):
+                 row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None, gnb=None,
+                 gn_part_groups: int = 0):
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
     (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
     sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res.
@@ -58,7 +59,9 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     act2: also return act2(result) as a second tensor (the result itself without activation): returns (raw, y).
     c0_used: promise that only the first c0_used (1..4) channels of x0 are non-zero (zero-padded image tensors).
     gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
-    where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone."""
+    where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone.
+    gn_part_groups > 0: returns (raw, part) with part = fp32 [N][groups][tiles][2] per-tile sums (x, x^2) of the result for
+    gn_act_forward(stat_part=part), or None where the launch cannot deliver them (small images, odd shapes)."""
     n, ih, iw, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     assert x0.dtype == BF16 and x0.is_contiguous() and w.dtype == BF16 and w.is_contiguous()
@@ -75,7 +78,15 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      CoutW=(w.shape[1] if rows is None else (rows + 31) // 32 * 32), out_cs=(0 if f32_nchw else out.shape[3]),
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out), C0_used=c0_used)
-    y = stats = None
+    y = stats = part = None
+    if gn_part_groups > 0:
+        d.gn_part_groups = gn_part_groups
+        tiles = hip.lib().ddpm_conv_gn_part_tiles(C.byref(d))
+        if tiles > 0:
+            part = torch.empty(n, gn_part_groups, tiles, 2, device=x0.device, dtype=torch.float32)
+            d.gn_part = hip.ptr(part)
+        else:
+            d.gn_part_groups = 0
     if gnb is not None:
         g_raw, g_gamma, g_beta, g_groups, g_act, g_stats, g_part, g_draw = gnb
         d.gnb_raw, d.gnb_gamma, d.gnb_beta, d.gnb_stats = hip.ptr(g_raw), hip.ptr(g_gamma), hip.ptr(g_beta), hip.ptr(g_stats)
@@ -102,6 +113,8 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     _launch(lambda: hip.CONV_KERNEL_NAMES[hip.lib().ddpm_conv_last_kernel()], cost, lambda: hip.call("ddpm_conv_forward", C.byref(d), hip.stream()))
     if act2 is not None:
         return out, y
+    if gn_part_groups > 0:
+        return out, part
     return out if gn is None else (out, y, stats)
 
 
@@ -184,10 +197,11 @@ def _gn_scratch(d, backward: int, device) -> Optional[Tensor]:
 def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int, *,
                    res: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_scale: float = 1.0,
                    stats: Optional[Tensor] = None, out: Optional[Tensor] = None, eps: float = 1e-5, act_beta: Optional[Tensor] = None,
-                   fixed_stats: bool = False):
+                   fixed_stats: bool = False, stat_part: Optional[Tensor] = None):
     """x: NHWC bf16.  Returns (y, stats) with stats fp32 [N][G][2] (None when groups == 0).  act_beta: the activation's
     learnable scalar (a device fp32 tensor with one element), required for swish / hardswish.  fixed_stats: normalise with
-    the (mean, rstd) pairs given in `stats` instead of computing them."""
+    the (mean, rstd) pairs given in `stats` instead of computing them.  stat_part: fp32 [N][G][parts][2] partial sums of x
+    from the convolution that produced it (conv_forward(gn_part_groups=...)); large images then skip their statistics pass."""
     n, h, w, c = x.shape
     assert x.dtype == BF16 and x.is_contiguous()
     if out is None:
@@ -197,6 +211,9 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
     d = hip.GnDesc(x=hip.ptr(x), gamma=hip.ptr(gamma), beta=hip.ptr(beta), res=hip.ptr(res), mask=hip.ptr(mask), mask_scale=mask_scale,
                    y=hip.ptr(out), stats=hip.ptr(stats), dy=None, part=None, N=n, HW=h * w, C=c, G=groups,
                    act=act, eps=eps, act_beta=_scalar_ptr(act, act_beta), fixed_stats=int(fixed_stats))
+    if stat_part is not None:
+        assert stat_part.dtype == torch.float32 and stat_part.is_contiguous() and stat_part.shape[:2] == (n, groups) and stat_part.shape[3] == 2
+        d.stat_part, d.stat_parts = hip.ptr(stat_part), stat_part.shape[2]
     scratch = _gn_scratch(d, 0, x.device)
     _launch("gn_fwd_split_kernel" if scratch is not None else "gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream()))

@@ -163,9 +163,15 @@ typedef struct ddpm_conv_desc {
     int C0_used;               /* 0, or a promise that only the first C0_used (1..4) channels of in0 are non-zero (an image stored
                                 * zero-padded to 16 channels: the stem, and the head's data-gradient): lets a 3x3 convolution to 32
                                 * channels run on a kernel that reads only those. */
+    float* gn_part;            /* optional, large images: fp32 [N][gn_part_groups][T][2], T = ddpm_conv_gn_part_tiles(desc) > 0: every
+                                * output tile stores the sum and the sum of squares of its (rounded) results per normalisation
+                                * group, so that the GroupNorm that follows (ddpm_gn_desc.stat_part) needs no statistics pass of
+                                * its own over the tensor */
+    int gn_part_groups;
 } ddpm_conv_desc;
 int ddpm_conv_gn_fusable(const ddpm_conv_desc* d);
 int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d);
+int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d);
 
 /* y = act(conv(x) + bias) [* mask] [+ res] for every kind above. */
 int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream);
@@ -210,6 +216,10 @@ typedef struct ddpm_gn_desc {
                                * (ddpm_reduce_rows entry with scalar = 1). */
     int fixed_stats;          /* 1: `stats` holds the statistics to normalise with (forward computes none; backward treats them
                                * as constants): BatchNorm2d in eval mode */
+    const float* stat_part;   /* forward, optional: fp32 [N][G][stat_parts][2] partial sums (x, x^2) of the tensor, written by the
+                               * convolution that produced it (ddpm_conv_desc.gn_part): where the many-workgroup path runs
+                               * (ddpm_gn_scratch_floats > 0 and `scratch` given) its statistics launch is skipped */
+    int stat_parts;
 } ddpm_gn_desc;
 
 /* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:

@@ -422,3 +422,51 @@ def test_conv_img_dgrad_with_fused_groupnorm_backward(dev, kind, n, c0, c, hw, g
     assert_rel(dx1.float().cpu(), dx0.float().cpu())
     torch.testing.assert_close(part1.cpu(), part0.cpu(), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(dsum1.cpu(), dsum0.cpu(), rtol=1e-2, atol=2e-2 * max(1.0, hw / 8))
+
+
+@pytest.mark.parametrize("kind,n,ci,co,h,wd,groups,act", [
+    (hip.CONV_3X3_S1, 2, 32, 32, 64, 64, 4, "gelu"),       # 8 channels per group, several tiles per image
+    (hip.CONV_1X1, 3, 32, 128, 64, 64, 4, "silu"),         # expansion of an inverted-residual block
+    (hip.CONV_1X1, 1, 128, 32, 128, 128, 4, "none"),       # projection
+    (hip.CONVT_2X2_S2, 2, 64, 32, 32, 32, 4, "gelu"),      # four position classes
+    (hip.CONV_3X3_S1, 1, 64, 64, 64, 128, 8, "relu"),      # non-square
+    (hip.CONV_1X1, 2, 32, 64, 128, 128, 16, "gelu"),       # 4 channels per group (the UNet's 16 groups at 64 channels)
+    (hip.CONV_1X1, 2, 64, 32, 64, 64, 16, "none"),         # 2 channels per group
+    (hip.CONV_3X3_S1, 1, 32, 256, 64, 64, 4, "gelu"),      # 64 channels per group
+])
+def test_conv_leaves_groupnorm_sums_for_large_images(dev, kind, n, ci, co, h, wd, groups, act):
+    """Large images: every output tile of the convolution stores the sums of its results per normalisation group and the
+    GroupNorm that follows runs without its statistics pass.  The raw tensor is bit-equal to the plain launch; statistics
+    and output equal those of the two-pass GroupNorm up to fp32 summation order (1e-5 relative / one bf16 step), and
+    torch's F.group_norm within the bf16 tolerance."""
+    from oracle import ref_cpu as O
+    k = {hip.CONV_3X3_S1: 3, hip.CONV_1X1: 1, hip.CONVT_2X2_S2: 2}[kind]
+    wshape = (ci, co, k, k) if kind == hip.CONVT_2X2_S2 else (co, ci, k, k)
+    w = r16(hash_normal(wshape, 81) * (1.0 / (ci * k * k)) ** 0.5)
+    b = hash_normal((co,), 82) * 0.3
+    x = r16(hash_normal((n, ci, h, wd), 83))
+    gamma, beta = (1 + 0.3 * hash_normal((co,), 84)).to(dev), (0.3 * hash_normal((co,), 85)).to(dev)
+    xd, wp, bd = nhwc(x, dev), pack.pack_fwd(kind, w.to(dev)), b.to(dev)
+    raw, part = ops.conv_forward(kind, xd, wp, bd, co, gn_part_groups=groups)
+    assert part is not None and part.shape[:2] == (n, groups)
+    raw2 = ops.conv_forward(kind, xd, wp, bd, co)
+    assert torch.equal(raw, raw2)
+    # the partial sums add up to the sums of the stored tensor
+    g = raw.float().view(n, -1, groups, co // groups)
+    torch.testing.assert_close(part[..., 0].sum(2), g.sum((1, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(part[..., 1].sum(2), (g * g).sum((1, 3)), rtol=1e-4, atol=1e-2)
+    y, stats = ops.gn_act_forward(raw, gamma, beta, groups, hip.ACT[act], stat_part=part)
+    y2, stats2 = ops.gn_act_forward(raw2, gamma, beta, groups, hip.ACT[act])
+    torch.testing.assert_close(stats, stats2, rtol=1e-5, atol=1e-6)
+    assert_rel(y.float().cpu(), y2.float().cpu(), 8e-3)
+    y_ref = F.group_norm(nchw(raw), groups, gamma.cpu(), beta.cpu(), eps=1e-5)
+    assert_rel(nchw(y), y_ref if act == "none" else O.act_fn(act)(y_ref), 1e-2)
+
+
+def test_conv_groupnorm_sums_are_declined_where_they_do_not_apply(dev):
+    """small images (whole-image kernels / single-pass GroupNorm) and one-channel groups get no partial sums"""
+    w = pack.pack_fwd(hip.CONV_1X1, torch.zeros(32, 32, 1, 1, device=dev))
+    for shape, groups in (((2, 16, 16, 32), 4), ((1, 64, 64, 32), 32), ((1, 60, 68, 32), 4)):
+        x = torch.zeros(shape, device=dev, dtype=torch.bfloat16)
+        raw, part = ops.conv_forward(hip.CONV_1X1, x, w, None, 32, gn_part_groups=groups)
+        assert part is None and raw.shape == shape
