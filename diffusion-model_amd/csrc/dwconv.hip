@@ -9,10 +9,14 @@
 
 // One thread produces PX horizontally adjacent pixels x 8 channels: per kernel row it loads the PX+2 input
 // vectors once and reuses them across the PX outputs, and loads the row's 3x8 weights once.
-template <int PX>
+// STATS (large images, host-checked shapes): every round of 256 work items lies inside one image and covers all channels;
+// the workgroup adds the sums (x, x^2) of what it stored per normalisation group and leaves them as one partial pair per
+// (image, group, round) in part[N][G][PT][2] for the GroupNorm that follows (ddpm_gn_desc.stat_part).
+template <int PX, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, bf16* __restrict__ y, int N, int H, int W,
-                                                         int C) {
+                                                         int C, float* __restrict__ part = nullptr, int G = 0, int PT = 0) {
+    __shared__ float s_red[STATS ? 4 * 64 * 8 : 1];
     const int cvs = C / 8, wq = W / PX;
     const long long total = (long long)N * H * wq * cvs;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -54,14 +58,75 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[q][j] += (float)v[q + kw][j] * wk[kw][j];
         }
+        float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_ss[4] = {0.f, 0.f, 0.f, 0.f};       // STATS: sums of this thread's four channel pairs
 #pragma unroll
         for (int q = 0; q < PX; ++q) {
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[q][j];
             *(bf16x8*)(y + ((n * H + hy) * W + wx + q) * C + c) = o;
+            if constexpr (STATS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+            }
+        }
+        if constexpr (STATS) {
+            // lanes with the same channel vector (lane % cvs, cvs a power of two <= 64) add up by shuffles, the four waves
+            // meet in LDS, one thread per group adds its channel pairs in a fixed order (deterministic)
+            for (int o = cvs; o < 64; o <<= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { st_s[q] += __shfl_xor(st_s[q], o); st_ss[q] += __shfl_xor(st_ss[q], o); }
+            }
+            const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+            __syncthreads();                               // the previous round's sums have been read
+            if (lane < cvs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { s_red[(wv * cvs + lane) * 8 + q] = st_s[q]; s_red[(wv * cvs + lane) * 8 + 4 + q] = st_ss[q]; }
+            }
+            __syncthreads();
+            const int cpg = C / G;
+            if (tid < G) {
+                float S = 0.f, SS = 0.f;
+                for (int c2 = tid * cpg / 2; c2 < (tid + 1) * cpg / 2; ++c2) {
+                    const int col = c2 >> 2, q = c2 & 3;
+#pragma unroll
+                    for (int wq_ = 0; wq_ < 4; ++wq_) { S += s_red[(wq_ * cvs + col) * 8 + q]; SS += s_red[(wq_ * cvs + col) * 8 + 4 + q]; }
+                }
+                const long long round = (i - tid) / 256;
+                const long long img = round / PT;
+                float* o = part + ((img * G + tid) * PT + (round - img * PT)) * 2;
+                o[0] = S; o[1] = SS;
+            }
         }
     }
+}
+
+// partial pairs per (image, group) that ddpm_dwconv3x3_forward_stats writes; 0 where it does not apply (small images, shapes
+// whose rounds of 256 work items would straddle images, one-channel groups)
+extern "C" int ddpm_dwconv3x3_stat_parts(int N, int H, int W, int C, int groups) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || groups <= 0 || groups > 256 || C % groups) return 0;
+    const int cpg = C / groups, cvs = C / 8;
+    if (cpg < 2 || (cpg & (cpg - 1)) || cvs > 64 || (cvs & (cvs - 1))) return 0;
+    if ((long long)H * W < 4096) return 0;
+    const int px = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
+    const long long per_image = (long long)H * (W / px) * cvs;
+    if (per_image % 256 || per_image / 256 > (1 << 20)) return 0;
+    return (int)(per_image / 256);
+}
+
+extern "C" int ddpm_dwconv3x3_forward_stats(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
+                                            int groups, float* part, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && w && y && part, "dwconv: null pointer");
+    const int PT = ddpm_dwconv3x3_stat_parts(N, H, W, C, groups);
+    DDPM_REQUIRE(PT > 0, "dwconv: no GroupNorm sums for N=%d %dx%d C=%d groups=%d (ask ddpm_dwconv3x3_stat_parts first)", N, H, W, C, groups);
+    const int px = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
+    long long grid = (long long)N * PT;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (px == 4) hipLaunchKernelGGL((dwconv3x3_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
+    else if (px == 2) hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
+    return ddpm_check_launch("dwconv3x3 (with GroupNorm sums)");
 }
 
 extern "C" int ddpm_dwconv3x3_forward(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -73,9 +138,9 @@ extern "C" int ddpm_dwconv3x3_forward(const void* x, const float* w, const float
     const long long total = (long long)N * H * (W / px) * (C / 8);
     long long grid = (total + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
-    if (px == 4) hipLaunchKernelGGL(dwconv3x3_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
-    else if (px == 2) hipLaunchKernelGGL(dwconv3x3_kernel<2>, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
-    else hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C);
+    if (px == 4) hipLaunchKernelGGL((dwconv3x3_kernel<4, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, (float*)nullptr, 0, 0);
+    else if (px == 2) hipLaunchKernelGGL((dwconv3x3_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, (float*)nullptr, 0, 0);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<1, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, (float*)nullptr, 0, 0);
     return ddpm_check_launch("dwconv3x3");
 }
 

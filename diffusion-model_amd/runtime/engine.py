@@ -539,10 +539,11 @@ class UNetEngine:
         def dw_unit(pre: str, xin: Var, out_mask) -> Var:
             """depthwise 3x3 -> GroupNorm -> act [-> * out_mask]   (conv_block.py:77-96)"""
             name, norm = pre + "depthwise.1", pre + "depthwise.2"
-            raw = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"])
+            raw, spart = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"], gn_part_groups=sp.groups) if self.conv_stats else (
+                ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"]), None)
             gamma, beta = P[norm + ".weight"], P[norm + ".bias"]
             y, stats = ops.gn_act_forward(raw, gamma, beta, sp.groups, sp.act, mask=out_mask, mask_scale=mscale,
-                                          act_beta=act_scalar(act_site(norm), sp.act))
+                                          act_beta=act_scalar(act_site(norm), sp.act), stat_part=spart)
             out = Var(y)
             if tape is not None:
                 tape.append(dw_bwd(pre, xin, raw, out, stats, out_mask))

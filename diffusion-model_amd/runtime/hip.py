@@ -138,6 +138,8 @@ _PROTOS = {
     "ddpm_bn_update_running": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp], _i),
     "ddpm_bn_eval_stats": ([_vp, _vp, _vp, _i, _f, _vp], _i),
     "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "ddpm_dwconv3x3_stat_parts": ([_i, _i, _i, _i, _i], _i),
+    "ddpm_dwconv3x3_forward_stats": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),
     "ddpm_reduce_rows": ([_vp, _vp, _vp, _i, _i, _vp], _i),

@@ -487,15 +487,22 @@ def sample_norm_backward(a: Tensor, b: Optional[Tensor], dy: Tensor, act: int, g
     return du, (da if act else du)
 
 
-def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
-    """x: NHWC bf16; w9c: fp32 [9][C] tap-major."""
+def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None, gn_part_groups: int = 0):
+    """x: NHWC bf16; w9c: fp32 [9][C] tap-major.  gn_part_groups > 0: returns (y, part) with part = fp32 [N][groups][parts][2]
+    partial sums (x, x^2) of y for gn_act_forward(stat_part=part), or None where the launch cannot deliver them."""
     n, h, w, c = x.shape
     assert x.dtype == BF16 and x.is_contiguous() and w9c.shape == (9, c) and w9c.dtype == torch.float32
     if out is None:
         out = torch.empty_like(x)
-    _launch("dwconv3x3_kernel", lambda: (_nb(x, w9c, bias, out), 18.0 * x.numel(), f"{h}x{w} C{c}"),
-            lambda: hip.call("ddpm_dwconv3x3_forward", hip.ptr(x), hip.ptr(w9c), hip.ptr(bias), hip.ptr(out), n, h, w, c, hip.stream()))
-    return out
+    parts = hip.lib().ddpm_dwconv3x3_stat_parts(n, h, w, c, gn_part_groups) if gn_part_groups > 0 else 0
+    cost = lambda: (_nb(x, w9c, bias, out), 18.0 * x.numel(), f"{h}x{w} C{c}")  # noqa: E731
+    if parts > 0:
+        part = torch.empty(n, gn_part_groups, parts, 2, device=x.device, dtype=torch.float32)
+        _launch("dwconv3x3_kernel", cost, lambda: hip.call("ddpm_dwconv3x3_forward_stats", hip.ptr(x), hip.ptr(w9c), hip.ptr(bias), hip.ptr(out),
+                                                           n, h, w, c, gn_part_groups, hip.ptr(part), hip.stream()))
+        return out, part
+    _launch("dwconv3x3_kernel", cost, lambda: hip.call("ddpm_dwconv3x3_forward", hip.ptr(x), hip.ptr(w9c), hip.ptr(bias), hip.ptr(out), n, h, w, c, hip.stream()))
+    return (out, None) if gn_part_groups > 0 else out
 
 
 def dwconv3x3_wgrad_blocks(n: int, h: int, w: int, c: int) -> int:

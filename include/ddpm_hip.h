@@ -254,6 +254,12 @@ int ddpm_bn_eval_stats(const float* running_mean, const float* running_var, floa
  * Also computes the data-gradient when given the tap-flipped weights and no bias. */
 int ddpm_dwconv3x3_forward(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                            ddpm_stream_t stream);
+/* The same convolution for large images, leaving the GroupNorm sums of conv_block.py:89 behind: part = fp32
+ * [N][groups][T][2] partial sums (x, x^2) of the result, T = ddpm_dwconv3x3_stat_parts(...) > 0 (0: not available for the
+ * shape), for ddpm_gn_desc.stat_part. */
+int ddpm_dwconv3x3_stat_parts(int N, int H, int W, int C, int groups);
+int ddpm_dwconv3x3_forward_stats(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
+                                 int groups, float* part, ddpm_stream_t stream);
 /* Per-workgroup partial sums of the depthwise weight/bias gradient: part[b][t][c], t = 0..8 the taps of
  * dw (sum dy * shifted x), t = 9 the bias (sum dy); b < ddpm_dwconv3x3_wgrad_blocks(N,H,W,C).  Every element is written. */
 int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* part, int N, int H, int W, int C, ddpm_stream_t stream);

@@ -83,6 +83,35 @@ def test_depthwise_fwd_dgrad_wgrad(dev, n, c, h, w_):
     assert_rel(tot[9].cpu(), gb, 5e-3)
 
 
+@pytest.mark.parametrize("n,c,h,w_,groups,act", [(2, 64, 128, 128, 16, "gelu"), (3, 128, 64, 64, 16, "silu"), (1, 32, 64, 96, 16, "gelu"),
+                                                 (2, 256, 64, 64, 4, "relu"), (1, 64, 64, 66, 16, "gelu")])
+def test_depthwise_leaves_groupnorm_sums_for_large_images(dev, n, c, h, w_, groups, act):
+    """Large images: the depthwise launch stores partial sums of its result per normalisation group, and the GroupNorm that
+    follows skips its statistics pass.  Result bit-equal to the plain launch; statistics equal up to fp32 summation order
+    (1e-5), the normalised tensor within one bf16 step of the two-pass result and within 1e-2 of torch's F.group_norm."""
+    x = r16(hash_normal((n, c, h, w_), 11))
+    w = hash_normal((c, 1, 3, 3), 12) * 0.3
+    b = hash_normal((c,), 13) * 0.2
+    gamma, beta = (1 + 0.3 * hash_normal((c,), 14)).to(dev), (0.3 * hash_normal((c,), 15)).to(dev)
+    w9 = w.view(c, 9).t().contiguous().to(dev)
+    xd = nhwc(x, dev)
+    y, part = ops.dwconv3x3(xd, w9, b.to(dev), gn_part_groups=groups)
+    y2 = ops.dwconv3x3(xd, w9, b.to(dev))
+    assert part is not None and part.shape[:2] == (n, groups) and torch.equal(y, y2)
+    g = y.float().view(n, -1, groups, c // groups)
+    torch.testing.assert_close(part[..., 0].sum(2), g.sum((1, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(part[..., 1].sum(2), (g * g).sum((1, 3)), rtol=1e-4, atol=1e-2)
+    z, stats = ops.gn_act_forward(y, gamma, beta, groups, hip.ACT[act], stat_part=part)
+    z2, stats2 = ops.gn_act_forward(y2, gamma, beta, groups, hip.ACT[act])
+    torch.testing.assert_close(stats, stats2, rtol=1e-5, atol=1e-6)
+    assert_rel(z.float().cpu(), z2.float().cpu(), 8e-3)
+    assert_rel(nchw(z), O.act_fn(act)(F.group_norm(nchw(y), groups, gamma.cpu(), beta.cpu(), eps=1e-5)), 1e-2)
+    # declined: small images, rounds of work items that would straddle images, one-channel groups
+    for shape, gr in (((2, 16, 16, 64), 16), ((1, 66, 66, 8), 4), ((1, 64, 64, 32), 32)):
+        _, none = ops.dwconv3x3(torch.zeros(shape, device=dev, dtype=torch.bfloat16), torch.zeros(9, shape[3], device=dev), None, gn_part_groups=gr)
+        assert none is None
+
+
 WG_CASES = [
     (hip.CONV_3X3_S1, 2, 32, 32, 16, 16),
     (hip.CONV_3X3_S1, 3, 64, 32, 8, 8),
