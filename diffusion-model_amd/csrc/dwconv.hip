@@ -7,6 +7,8 @@
 #include "common.h"
 #include "ddpm_hip.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // One thread produces PX horizontally adjacent pixels x 8 channels: per kernel row it loads the PX+2 input
 // vectors once and reuses them across the PX outputs, and loads the row's 3x8 weights once.
 // STATS (large images, host-checked shapes): every round of 256 work items lies inside one image and covers all channels;
@@ -19,30 +21,53 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__
     __shared__ float s_red[STATS ? 4 * 64 * 8 : 1];
     const int cvs = C / 8, wq = W / PX;
     const long long total = (long long)N * H * wq * cvs;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % cvs);
-        long long r = i / cvs;
-        const int wx = (int)(r % wq) * PX; r /= wq;
-        const int hy = (int)(r % H);
-        const long long n = r / H;
-        const int c = cv * 8;
+    // Workgroups are dealt to the 8 XCDs in turn and every XCD has an L2 of its own: neighbouring image rows (whose halo
+    // rows are shared) go to workgroups of the SAME XCD, so that the three uses of an input row hit one L2.
+#ifndef DW_NO_XCD_MAP
+    const unsigned nb = gridDim.x;
+    const unsigned lb = nb % 8 == 0 ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+#else
+    const unsigned lb = blockIdx.x;
+#endif
+    // (the host has checked that the item count fits 32 bits: the index arithmetic of an item is a handful of 32-bit operations)
+    for (unsigned i = lb * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+        const unsigned cv = i % (unsigned)cvs;
+        unsigned r = i / (unsigned)cvs;
+        const int wx = (int)(r % (unsigned)wq) * PX; r /= (unsigned)wq;
+        const int hy = (int)(r % (unsigned)H);
+        const long long n = r / (unsigned)H;
+        const int c = (int)cv * 8;
         float acc[PX][8];
+        if (bias) {
+            const f32x4 b0 = *(const f32x4*)(bias + c), b1 = *(const f32x4*)(bias + c + 4);
 #pragma unroll
-        for (int q = 0; q < PX; ++q)
+            for (int q = 0; q < PX; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[q][j] = bias ? bias[c + j] : 0.f;
+                for (int j = 0; j < 4; ++j) { acc[q][j] = b0[j]; acc[q][4 + j] = b1[j]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PX; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int iy = hy + kh - 1;
             if (iy < 0 || iy >= H) continue;
             const bf16* row = x + ((n * H + iy) * W) * C + c;
-            bf16x8 v[PX + 2];
+            // the PX+2 input vectors of this kernel row as raw 16-byte words; only the two outer ones can lie outside the row
+            // (their address is clamped and the value replaced by zero)
+            u32x4 u[PX + 2];
 #pragma unroll
             for (int q = 0; q < PX + 2; ++q) {
                 const int ix = wx + q - 1;
+                const int ixc = q == 0 ? (ix < 0 ? 0 : ix) : (q == PX + 1 ? (ix >= W ? W - 1 : ix) : ix);
+                u[q] = *(const u32x4*)(row + (long long)ixc * C);
+                if (q == 0 || q == PX + 1) {
+                    const bool ok = ix >= 0 && ix < W;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[q][j] = (bf16)0.f;
-                if (ix >= 0 && ix < W) v[q] = *(const bf16x8*)(row + (long long)ix * C);
+                    for (int k = 0; k < 4; ++k) u[q][k] = ok ? u[q][k] : 0u;
+                }
             }
             float wk[3][8];
 #pragma unroll
@@ -51,12 +76,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { wk[kw][j] = w0[j]; wk[kw][4 + j] = w1[j]; }
             }
+            // every input vector is unpacked once (bf16 -> fp32 is a shift or a mask of the packed word) and feeds the up to
+            // three outputs it belongs to; per output the taps are still added in (kh, kw) order
 #pragma unroll
-            for (int q = 0; q < PX; ++q)
+            for (int pq = 0; pq < PX + 2; ++pq) {
+                float f[8];
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+                for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(u[pq][k] << 16); f[2 * k + 1] = __uint_as_float(u[pq][k] & 0xffff0000u); }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[q][j] += (float)v[q + kw][j] * wk[kw][j];
+                for (int kw = 2; kw >= 0; --kw) {
+                    const int q = pq - kw;
+                    if (q < 0 || q >= PX) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[q][j] += f[j] * wk[kw][j];
+                }
+            }
         }
         float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_ss[4] = {0.f, 0.f, 0.f, 0.f};       // STATS: sums of this thread's four channel pairs
 #pragma unroll
@@ -120,9 +154,11 @@ extern "C" int ddpm_dwconv3x3_forward_stats(const void* x, const float* w, const
     DDPM_REQUIRE(x && w && y && part, "dwconv: null pointer");
     const int PT = ddpm_dwconv3x3_stat_parts(N, H, W, C, groups);
     DDPM_REQUIRE(PT > 0, "dwconv: no GroupNorm sums for N=%d %dx%d C=%d groups=%d (ask ddpm_dwconv3x3_stat_parts first)", N, H, W, C, groups);
+    DDPM_REQUIRE((long long)N * PT * 256 + 256ll * 4096 < (1ll << 32), "dwconv: %lld work items do not fit the kernel's 32-bit index", (long long)N * PT * 256);
     const int px = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
     long long grid = (long long)N * PT;
     if (grid > 256 * 16) grid = 256 * 16;
+    if (grid > 8) grid = (grid + 7) / 8 * 8;
     if (px == 4) hipLaunchKernelGGL((dwconv3x3_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
     else if (px == 2) hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
     else hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
@@ -136,8 +172,10 @@ extern "C" int ddpm_dwconv3x3_forward(const void* x, const float* w, const float
     DDPM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "dwconv: C (%d) must be a positive multiple of 8", C);
     const int px = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
     const long long total = (long long)N * H * (W / px) * (C / 8);
+    DDPM_REQUIRE(total + 256ll * 4096 < (1ll << 32), "dwconv: %lld work items do not fit the kernel's 32-bit index", total);
     long long grid = (total + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
+    if (grid > 8) grid = (grid + 7) / 8 * 8;              // whole rounds over the XCDs (surplus workgroups find no work)
     if (px == 4) hipLaunchKernelGGL((dwconv3x3_kernel<4, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, (float*)nullptr, 0, 0);
     else if (px == 2) hipLaunchKernelGGL((dwconv3x3_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, (float*)nullptr, 0, 0);
     else hipLaunchKernelGGL((dwconv3x3_kernel<1, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, N, H, W, C, (float*)nullptr, 0, 0);
