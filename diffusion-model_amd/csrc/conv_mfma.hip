@@ -32,6 +32,8 @@ struct ConvArgs {
     float* sum_out;                  // optional fp32 [N][Cout] per-image sums of the activated output (atomics)
     bf16* out2; int act2;            // optional second result act2(out), same layout: a unit without normalisation keeps its
                                      // pre-activation for the backward pass and hands the activated tensor on
+    const float* in_gn; int in_gn_act; // optional (PRE kernels): in0 is a raw tensor whose GroupNorm + activation is applied on load:
+                                     // fp32 [N][C0][2] = (scale, shift) per image and channel, then the activation
     float* gn_part; int gn_G, gn_PT; // optional (STATS kernels): per (image, group, output tile) sums of the rounded result and of
                                      // its squares, fp32 [N][gn_G][gn_PT][2]: what the GroupNorm that follows needs, without a
                                      // statistics pass over the tensor
@@ -57,7 +59,7 @@ extern "C" int ddpm_conv_set_dbg(unsigned long long* p) {
 #define CONV_STAMP(i)
 #endif
 
-template <int WM, int WN, int NT, bool STATS = false>
+template <int WM, int WN, int NT, bool STATS = false, bool PRE = false>
 __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int T = 256, BM = 32 * WM, BNW = 32 * NT, BN = BNW * WN;
     constexpr int OS = BN * 2 + 16;   // epilogue LDS row stride (bytes)
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
         const bool src1 = c0 >= a.C0;
         const bf16* src = src1 ? a.in1 : a.in0;
         const int cs = src1 ? a.C1 : a.C0, cc = src1 ? c0 - a.C0 : c0;
-        const bool xform = !src1 && (a.in_add || a.in_mask);
+        const bool xform = !src1 && (a.in_add || a.in_mask || (PRE && a.in_gn));
         // one item = one 16-byte piece (part) of a row; rows 0 .. npix-1 are patch pixels, the rest weight rows.  A
         // thread keeps its piece index and walks rows in steps of 64, all in 32-bit arithmetic (the host checks the ranges).
         const int part = tid & 3, n_rows = npix + ntaps * BN;
@@ -160,6 +162,27 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
 #pragma unroll
                     for (int u = 0; u < STAGE_U; ++u) {
                         if (pl[u] < 0) continue;
+                        if constexpr (PRE) {
+                            if (a.in_gn) {
+                                // normalise + activate what the producer left raw, rounded to bf16 as a GroupNorm launch would
+                                // have stored it (padding pixels stay zero: the padding belongs to the normalised tensor)
+                                const int n = n0 + div_fast(rb + u * 64, g.phw_magic);
+                                const f32x4* af = (const f32x4*)(a.in_gn + ((long long)n * a.C0 + cc + part * 8) * 2);
+                                float sc[8], sh[8];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { const f32x4 t = af[k]; sc[2 * k] = t[0]; sh[2 * k] = t[1]; sc[2 * k + 1] = t[2]; sh[2 * k + 1] = t[3]; }
+                                if (a.in_gn_act == ACT_GELU) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[u][j] = (bf16)act_fwd((float)v[u][j] * sc[j] + sh[j], ACT_GELU);
+                                } else if (a.in_gn_act == ACT_SILU) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[u][j] = (bf16)act_fwd((float)v[u][j] * sc[j] + sh[j], ACT_SILU);
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[u][j] = (bf16)((float)v[u][j] * sc[j] + sh[j]);
+                                }
+                            }
+                        }
                         if (a.in_add) {
                             const int n = n0 + div_fast(rb + u * 64, g.phw_magic);
                             const float* ad = a.in_add + n * a.C0 + cc + part * 8;
@@ -374,10 +397,10 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <int WM, int WN, int NT, bool STATS = false>
+template <int WM, int WN, int NT, bool STATS = false, bool PRE = false>
 static int launch_conv(const ConvArgs& a, size_t lds, hipStream_t stream) {
     const ConvGeom& g = a.g;
-    auto k = conv_mfma_kernel<WM, WN, NT, STATS>;
+    auto k = conv_mfma_kernel<WM, WN, NT, STATS, PRE>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ddpm_check_launch("conv: raise dynamic LDS limit");
@@ -414,6 +437,11 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
+    if (d->in_affine && !d->gn_part) {
+        // normalise-on-load exists in the general kernel only
+        DDPM_REQUIRE(!d->gn_gamma && !d->gnb_raw, "conv: normalise-on-load does not combine with the fused GroupNorm launches");
+        return conv_general(d, stream);
+    }
     if (d->gn_part) {
         // per-tile GroupNorm sums come from the general kernel's epilogue only (large images, where the GroupNorm that follows
         // takes its many-workgroup path): the caller has asked ddpm_conv_gn_part_tiles first
@@ -490,6 +518,9 @@ static int conv_general(const ddpm_conv_desc* d, hipStream_t stream) {
     a.out_mask = d->out_mask; a.out_mask_scale = d->out_mask_scale;
     a.Cout = d->Cout; a.CoutW = d->CoutW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.out_mode = d->out_mode; a.sum_out = d->sum_out;
     a.out2 = (bf16*)d->out2; a.act2 = d->act2;
+    a.in_gn = d->in_affine; a.in_gn_act = d->in_affine_act;
+    DDPM_REQUIRE(!d->in_affine || (!d->in_add && d->C1 == 0 && (d->in_affine_act == ACT_NONE || d->in_affine_act == ACT_GELU || d->in_affine_act == ACT_SILU)),
+                 "conv: normalise-on-load takes one input tensor, no broadcast add, and none / gelu / silu as activation");
     a.gn_part = d->gn_part; a.gn_G = d->gn_part_groups; a.gn_PT = a.g.ncls * a.g.tiles_h * a.g.tiles_w;
     DDPM_REQUIRE(!d->out2 || (d->out_mode == OUT_BF16_NHWC && d->Cout % 8 == 0 && d->act == 0), "conv: the second (activated) result needs an NHWC bf16 output, Cout %% 8 == 0 and no first activation");
     DDPM_REQUIRE(!ACT_HAS_BETA(d->act) && !ACT_HAS_BETA(d->act2) && !ACT_HAS_BETA(d->gn_act) && !ACT_HAS_BETA(d->gnb_act),
@@ -504,6 +535,12 @@ static int conv_general(const ddpm_conv_desc* d, hipStream_t stream) {
     if (lds < lds_out) lds = lds_out;
     DDPM_REQUIRE(lds <= 160 * 1024, "conv: tile needs %zu B of LDS", lds);
 
+    if (a.in_gn) {
+        if (a.gn_part && lds < 4 * 16 * 8 * sizeof(float)) lds = 4 * 16 * 8 * sizeof(float);
+#define CONV_CASE(WMv, WNv, NTv) if (cfg.wm == WMv && cfg.wn == WNv && cfg.nt == NTv) return a.gn_part ? launch_conv<WMv, WNv, NTv, true, true>(a, lds, stream) : launch_conv<WMv, WNv, NTv, false, true>(a, lds, stream);
+        CONV_CASE(4, 1, 4) CONV_CASE(4, 1, 2) CONV_CASE(2, 2, 2) CONV_CASE(4, 1, 1) CONV_CASE(2, 2, 1)
+#undef CONV_CASE
+    }
     if (a.gn_part) {
         if (lds < 4 * 16 * 8 * sizeof(float)) lds = 4 * 16 * 8 * sizeof(float);
 #define CONV_CASE(WMv, WNv, NTv) if (cfg.wm == WMv && cfg.wn == WNv && cfg.nt == NTv) return launch_conv<WMv, WNv, NTv, true>(a, lds, stream);

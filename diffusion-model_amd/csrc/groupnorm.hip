@@ -776,6 +776,38 @@ extern "C" int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream_)
     return ddpm_check_launch("gn_forward");
 }
 
+// One wave per (image, group): the lanes share out the producer's partial pairs, add them up in a fixed order and write the
+// group's statistics and the (scale, shift) pair of each of its channels.
+__global__ __launch_bounds__(64) void gn_fold_affine_kernel(const float* __restrict__ sp, int NP, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int HW, int C, int G, float eps,
+                                                            float* __restrict__ stats, float* __restrict__ affine) {
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G, lane = threadIdx.x;
+    const int cpg = C / G;
+    const float2* in = (const float2*)sp + (long long)blockIdx.x * NP;
+    float S = 0.f, SS = 0.f;
+    for (int q = lane; q < NP; q += 64) { const float2 v = in[q]; S += v.x; SS += v.y; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { S += __shfl_xor(S, o); SS += __shfl_xor(SS, o); }
+    const float m = 1.0f / (float)(cpg * HW);
+    const float mean = S * m;
+    const float rstd = rsqrtf(fmaxf(SS * m - mean * mean, 0.f) + eps);
+    if (lane == 0 && stats) { stats[(long long)blockIdx.x * 2] = mean; stats[(long long)blockIdx.x * 2 + 1] = rstd; }
+    for (int c = lane; c < cpg; c += 64) {
+        const int ch = g * cpg + c;
+        const float ga = gamma[ch] * rstd;
+        float* o = affine + ((long long)n * C + ch) * 2;
+        o[0] = ga; o[1] = beta[ch] - mean * ga;
+    }
+}
+
+extern "C" int ddpm_gn_fold_affine(const float* stat_part, int parts, const float* gamma, const float* beta, int N, int HW, int C, int G,
+                                   float eps, float* stats, float* affine, ddpm_stream_t stream_) {
+    DDPM_REQUIRE(stat_part && gamma && beta && affine, "gn_fold_affine: null pointer");
+    DDPM_REQUIRE(parts > 0 && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "gn_fold_affine: bad shape (parts %d, N %d, HW %d, C %d, G %d)", parts, N, HW, C, G);
+    hipLaunchKernelGGL(gn_fold_affine_kernel, dim3((unsigned)(N * G)), dim3(64), 0, (hipStream_t)stream_, stat_part, parts, gamma, beta, HW, C, G, eps, stats, affine);
+    return ddpm_check_launch("gn_fold_affine");
+}
+
 extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GnArgs a;

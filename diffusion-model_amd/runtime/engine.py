@@ -26,6 +26,8 @@ from torch import Tensor
 from . import hip, ops, pack
 from .params import GradStore, WeightCache, conv_dims
 
+_LOADER_ACTS = (0, hip.ACT["gelu"], hip.ACT["silu"])   # activations the convolution loader can apply (normalise-on-load)
+
 # state_dict entries that are buffers of a BatchNorm2d, not parameters: they travel with the parameters but have no gradient
 BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
 
@@ -178,6 +180,7 @@ class UNetEngine:
         self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.conv_stats = os.environ.get("DDPM_CONV_STATS", "1") != "0"   # large images: GroupNorm sums from the convolution's tiles
+        self.norm_on_load = os.environ.get("DDPM_NORM_ON_LOAD", "1") != "0"  # inference, large images: GroupNorm + act in the consumer's loader
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
         self.phases = 1                 # backward in 1, 2 (decoder | encoder), 4 (each halved at its middle stage), 5 (the last
                                         # of those cut again after the first encoder convolution) or, for any larger value,
@@ -377,9 +380,10 @@ class UNetEngine:
         # ---- fused units ------------------------------------------------------------------------
         def conv_unit(name: str, x0: Var, *, x1: Optional[Var] = None, in_add: Optional[Var] = None, in_mask=None,
                       norm: Optional[str] = None, groups: int = 0, act: int = 0, res: Optional[Var] = None, out_mask=None,
-                      c0_used: int = 0) -> Var:
+                      c0_used: int = 0, in_affine=None) -> Var:
             """conv [-> GroupNorm] -> act [-> * out_mask] [+ res].  `norm` = parameter prefix of the GroupNorm.
-            c0_used: only that many leading channels of x0 are non-zero (the zero-padded image at the stem)."""
+            c0_used: only that many leading channels of x0 are non-zero (the zero-padded image at the stem).
+            in_affine = (affine, act), inference only: x0 is raw, its GroupNorm + activation run in this convolution's loader."""
             kind = sp.convs[name]
             wf = wc.fwd[name]
             bias = P[name + ".bias"]
@@ -392,7 +396,8 @@ class UNetEngine:
                                             in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, act=act, c0_used=c0_used))
             gamma = P[norm + ".weight"] if norm else None
             beta = P[norm + ".bias"] if norm else None
-            if bsc is None and norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
+            assert in_affine is None or (tape is None and norm and x1 is None and in_add is None)
+            if in_affine is None and bsc is None and norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
                 # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
                 raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                                  in_add=None if in_add is None else in_add.v,
@@ -409,7 +414,7 @@ class UNetEngine:
                 want = groups if (norm and self.conv_stats and not c0_used) else 0
                 raw = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                        in_add=None if in_add is None else in_add.v, in_mask=in_mask, in_scale=mscale, c0_used=c0_used,
-                                       gn_part_groups=want)
+                                       gn_part_groups=want, in_affine=in_affine)
                 raw, spart = raw if want else (raw, None)
                 y, stats = ops.gn_act_forward(raw, gamma, beta, groups if norm else 0, act, res=None if res is None else res.v,
                                               mask=out_mask, mask_scale=mscale, act_beta=bsc, stat_part=spart)
@@ -611,7 +616,20 @@ class UNetEngine:
                     tape.append(bwd)
                 return out
             e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
-            d = dw_unit(pre, e, m_d)
+            if (tape is None and m_d is None and self.conv_stats and self.norm_on_load and sp.act in _LOADER_ACTS
+                    and act_scalar(act_site(pre + "depthwise.2"), sp.act) is None):
+                # inference on large images: the depthwise result stays raw; its GroupNorm + activation run in the loader of
+                # the projection (one pass over the expanded tensor less)
+                raw, spart = ops.dwconv3x3(e.v, wc.dw[nd], P[nd + ".bias"], gn_part_groups=sp.groups)
+                if spart is not None:
+                    g2 = pre + "depthwise.2"
+                    _, affine = ops.gn_fold_affine(spart, P[g2 + ".weight"], P[g2 + ".bias"], hh * ww)
+                    return conv_unit(pre + "projection.1", Var(raw), norm=pre + "projection.2", groups=sp.groups, act=0, res=xin,
+                                     in_affine=(affine, sp.act))
+                y, _ = ops.gn_act_forward(raw, P[pre + "depthwise.2.weight"], P[pre + "depthwise.2.bias"], sp.groups, sp.act)
+                d = Var(y)
+            else:
+                d = dw_unit(pre, e, m_d)
             return conv_unit(pre + "projection.1", d, norm=pre + "projection.2", groups=sp.groups, act=0, res=xin)
 
         def embed(pre: str, sin: Var) -> Var:

@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("gn_gamma", _vp), ("gn_beta", _vp), ("gn_out", _vp), ("gn_stats", _vp), ("gn_res", _vp),
         ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("out2", _vp), ("act2", _i),
         ("gnb_raw", _vp), ("gnb_gamma", _vp), ("gnb_beta", _vp), ("gnb_stats", _vp), ("gnb_part", _vp), ("gnb_draw", _vp),
-        ("gnb_groups", _i), ("gnb_act", _i), ("C0_used", _i), ("gn_part", _vp), ("gn_part_groups", _i),
+        ("gnb_groups", _i), ("gnb_act", _i), ("C0_used", _i), ("gn_part", _vp), ("gn_part_groups", _i), ("in_affine", _vp), ("in_affine_act", _i),
     ]
 
 
@@ -133,6 +133,7 @@ _PROTOS = {
     "ddpm_gn_act_forward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_act_backward": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_scratch_floats": ([C.POINTER(GnDesc), _i], _i64),
+    "ddpm_gn_fold_affine": ([_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "ddpm_gn_act_forward_static": ([C.POINTER(GnDesc), _vp], _i),
     "ddpm_gn_static_scratch_floats": ([], _i64),
     "ddpm_bn_update_running": ([_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp], _i),

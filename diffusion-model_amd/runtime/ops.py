@@ -50,7 +50,7 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
                  out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
                  row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None, gnb=None,
-                 gn_part_groups: int = 0):
+                 gn_part_groups: int = 0, in_affine=None):
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
     (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
     sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res.
@@ -61,7 +61,9 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
     where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone.
     gn_part_groups > 0: returns (raw, part) with part = fp32 [N][groups][tiles][2] per-tile sums (x, x^2) of the result for
-    gn_act_forward(stat_part=part), or None where the launch cannot deliver them (small images, odd shapes)."""
+    gn_act_forward(stat_part=part), or None where the launch cannot deliver them (small images, odd shapes).
+    in_affine = (affine, act): x0 is the raw input of a GroupNorm + activation that has not been applied; affine = fp32
+    [N][C0][2] from gn_fold_affine, act = none / gelu / silu: the loader normalises and activates (inference on large images)."""
     n, ih, iw, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     assert x0.dtype == BF16 and x0.is_contiguous() and w.dtype == BF16 and w.is_contiguous()
@@ -79,6 +81,10 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out), C0_used=c0_used)
     y = stats = part = None
+    if in_affine is not None:
+        aff, aact = in_affine
+        assert aff.dtype == torch.float32 and aff.is_contiguous() and aff.shape == (n, c0, 2) and x1 is None and in_add is None
+        d.in_affine, d.in_affine_act = hip.ptr(aff), aact
     if gn_part_groups > 0:
         d.gn_part_groups = gn_part_groups
         tiles = hip.lib().ddpm_conv_gn_part_tiles(C.byref(d))
@@ -218,6 +224,19 @@ def gn_act_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], g
     _launch("gn_fwd_split_kernel" if scratch is not None else "gn_fwd_kernel", lambda: (_nb(x, res, mask, out, gamma, beta, stats), 0.0, f"{h}x{w} C{c} G{groups} a{act}"),
             lambda: hip.call("ddpm_gn_act_forward", C.byref(d), hip.stream()))
     return out, stats
+
+
+def gn_fold_affine(stat_part: Tensor, gamma: Tensor, beta: Tensor, hw: int, eps: float = 1e-5):
+    """stat_part: fp32 [N][G][parts][2] partial sums from the producing convolution.  Returns (stats [N][G][2], affine [N][C][2]):
+    the GroupNorm's statistics and the per-image (scale, shift) of every channel, for conv_forward(in_affine=...)."""
+    n, g, parts, _ = stat_part.shape
+    c = gamma.numel()
+    stats = torch.empty(n, g, 2, device=stat_part.device, dtype=torch.float32)
+    affine = torch.empty(n, c, 2, device=stat_part.device, dtype=torch.float32)
+    _launch("gn_fold_affine_kernel", lambda: (_nb(stat_part, stats, affine, gamma, beta), 0.0, f"N{n} C{c} G{g} parts{parts}"),
+            lambda: hip.call("ddpm_gn_fold_affine", hip.ptr(stat_part), parts, hip.ptr(gamma), hip.ptr(beta), n, hw, c, g, float(eps),
+                             hip.ptr(stats), hip.ptr(affine), hip.stream()))
+    return stats, affine
 
 
 def gn_act_backward(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, act: int,

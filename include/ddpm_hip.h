@@ -168,6 +168,11 @@ typedef struct ddpm_conv_desc {
                                 * group, so that the GroupNorm that follows (ddpm_gn_desc.stat_part) needs no statistics pass of
                                 * its own over the tensor */
     int gn_part_groups;
+    const float* in_affine;    /* optional, inference on large images: in0 is the RAW input of a GroupNorm + activation
+                                * (conv_block.py:89-96) that has not been applied: fp32 [N][C0][2] = (scale, shift) per image and
+                                * channel from ddpm_gn_fold_affine; the loader computes act(x * scale + shift), rounded to bf16 as
+                                * the GroupNorm launch would have stored it.  One input tensor, no in_add; in_mask applies after. */
+    int in_affine_act;         /* DDPM_ACT none / gelu / silu */
 } ddpm_conv_desc;
 int ddpm_conv_gn_fusable(const ddpm_conv_desc* d);
 int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d);
@@ -227,6 +232,12 @@ typedef struct ddpm_gn_desc {
 int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream);
 /* dx and the per-image partial sums of dgamma, dbeta, dbias of the above (no atomics: deterministic). */
 int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
+
+/* GroupNorm statistics from the producer's partial sums, as what a consumer needs to normalise on load: stat_part = fp32
+ * [N][G][parts][2] (ddpm_conv_desc.gn_part / ddpm_dwconv3x3_forward_stats) -> stats fp32 [N][G][2] (mean, rstd; optional) and
+ * affine fp32 [N][C][2] = (gamma * rstd, beta - mean * gamma * rstd) for ddpm_conv_desc.in_affine. */
+int ddpm_gn_fold_affine(const float* stat_part, int parts, const float* gamma, const float* beta, int N, int HW, int C, int G,
+                        float eps, float* stats, float* affine, ddpm_stream_t stream);
 /* floats of `scratch` the forward (backward = 0) or backward (1) call would use for this shape; 0 = none; -1 on error */
 int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward);
 /* ddpm_gn_act_forward for callers that cannot allocate or pass a workspace (code under HIP graph capture, tight serving

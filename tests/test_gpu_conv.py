@@ -470,3 +470,40 @@ def test_conv_groupnorm_sums_are_declined_where_they_do_not_apply(dev):
         x = torch.zeros(shape, device=dev, dtype=torch.bfloat16)
         raw, part = ops.conv_forward(hip.CONV_1X1, x, w, None, 32, gn_part_groups=groups)
         assert part is None and raw.shape == shape
+
+
+@pytest.mark.parametrize("n,ci,co,h,wd,groups,act,with_sums", [
+    (2, 64, 32, 128, 128, 16, "gelu", True),        # projection of an inverted-residual block at the first stage
+    (3, 128, 64, 64, 64, 16, "silu", True),
+    (2, 64, 32, 16, 16, 16, "gelu", False),         # small image: no partial sums for the output, the loader still normalises
+    (1, 256, 128, 64, 64, 16, "none", True),
+])
+def test_conv_normalises_and_activates_on_load(dev, n, ci, co, h, wd, groups, act, with_sums):
+    """Inference on large images: a 1x1 convolution reads the RAW result of the producer and applies its GroupNorm + activation
+    in the loader (scale / shift per image and channel from the producer's partial sums).  Against the three-launch path
+    (GroupNorm launch, then the convolution): the statistics agree to 1e-5, the result within one bf16 step of its scale (the
+    two paths add the partial sums in different orders), and against torch fp32 within the bf16 tolerance."""
+    from oracle import ref_cpu as O
+    x = r16(hash_normal((n, ci, h, wd), 91) * 1.3 + 0.4)
+    gamma, beta = (1 + 0.3 * hash_normal((ci,), 92)), (0.3 * hash_normal((ci,), 93))
+    w = r16(hash_normal((co, ci, 1, 1), 94) * (1.0 / ci) ** 0.5)
+    b = hash_normal((co,), 95) * 0.2
+    xd, wp, bd = nhwc(x, dev), pack.pack_fwd(hip.CONV_1X1, w.to(dev)), b.to(dev)
+    # the producer's partial sums: here from a plain reduction of x over arbitrary chunks of pixels
+    parts = 8
+    g = xd.float().view(n, parts, h * wd // parts, groups, ci // groups)
+    part = torch.stack([g.sum((2, 4)), (g * g).sum((2, 4))], -1).permute(0, 2, 1, 3).contiguous()     # [N][G][parts][2]
+    stats, affine = ops.gn_fold_affine(part, gamma.to(dev), beta.to(dev), h * wd)
+    y_gn, stats2 = ops.gn_act_forward(xd, gamma.to(dev), beta.to(dev), groups, hip.ACT[act])
+    torch.testing.assert_close(stats, stats2, rtol=1e-5, atol=1e-6)
+    ref = ops.conv_forward(hip.CONV_1X1, y_gn, wp, bd, co)
+    got = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=(affine, hip.ACT[act]), gn_part_groups=groups if with_sums else 0)
+    if with_sums:
+        got, opart = got
+        assert opart is not None
+        gg = got.float().view(n, -1, groups, co // groups)
+        torch.testing.assert_close(opart[..., 0].sum(2), gg.sum((1, 3)), rtol=1e-4, atol=1e-2)
+    assert_rel(got.float().cpu(), ref.float().cpu(), 8e-3)
+    a = (lambda v: v) if act == "none" else O.act_fn(act)
+    y_ref = F.conv2d(r16(a(F.group_norm(x, groups, gamma, beta, eps=1e-5))), w, b)
+    assert_rel(nchw(got), y_ref, 1e-2)
