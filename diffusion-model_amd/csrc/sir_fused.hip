@@ -379,9 +379,21 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
 // to overlap (4883 against 4688 sampled images/s).  The 8x8 / 4x4 shapes of wider networks spill more and showed no gain.
 constexpr int sir_fwd_waves(int c, int w) { return (c == 32 && w == 16) ? 4 : 2; }
 
-template <int C, int W>
-__global__ __launch_bounds__(SIR_THREADS, sir_fwd_waves(C, W)) void sir_fwd_kernel(const SirArgs a) {
+// LEAN = inference (nothing is saved for a backward pass, no dropout masks; the host checks): with the pointers known to be
+// null at compile time, the addresses, mask words and stores of the recording path leave the kernel (and its registers).
+template <bool LEAN>
+__device__ __forceinline__ SirArgs sir_lean_args(SirArgs a) {
+    if constexpr (LEAN) {
+        a.m_in = nullptr; a.m_e = nullptr; a.m_d = nullptr;
+        a.raw_e = nullptr; a.y_e = nullptr; a.st1 = nullptr; a.raw_d = nullptr; a.y_d = nullptr; a.st2 = nullptr; a.raw_o = nullptr; a.st3 = nullptr;
+    }
+    return a;
+}
+
+template <int C, int W, bool LEAN>
+__global__ __launch_bounds__(SIR_THREADS, sir_fwd_waves(C, W)) void sir_fwd_kernel(const SirArgs a_) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SirArgs a = sir_lean_args<LEAN>(a_);
     switch (a.act) {
         case ACT_GELU: sir_fwd_body<C, W, ACT_GELU>(a, smem); break;
         case ACT_SILU: sir_fwd_body<C, W, ACT_SILU>(a, smem); break;
@@ -502,6 +514,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
                 if (mask) z = (mk[k] >> j) & 1 ? z * a.mscale : 0.f;
                 o[j] = (bf16)z;
             }
+            asm volatile("" : "+v"(o));                    // one vector after the other: interleaved activation chains spill
             *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
             if (y_out) *(bf16x8*)(y_out + (row0 + row) * E + v1 * 8) = o;
         }
@@ -628,9 +641,10 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
     }
 }
 
-template <int C, int W>
-__global__ __launch_bounds__(SIR_THREADS) void sir_fwd_big_kernel(const SirArgs a) {
+template <int C, int W, bool LEAN>
+__global__ __launch_bounds__(SIR_THREADS) void sir_fwd_big_kernel(const SirArgs a_) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SirArgs a = sir_lean_args<LEAN>(a_);
     switch (a.act) {
         case ACT_GELU: sir_fwd_big_body<C, W, ACT_GELU>(a, smem); break;
         case ACT_SILU: sir_fwd_big_body<C, W, ACT_SILU>(a, smem); break;
@@ -638,12 +652,12 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_fwd_big_kernel(const SirArgs 
     }
 }
 
-template <int C, int W>
-static int sir_big_launch(const SirArgs& a, hipStream_t stream) {
+template <int C, int W, bool LEAN>
+static int sir_big_launch_as(const SirArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, M = W * W;
     constexpr int lds = M * (E * 2 + 16) + ((SIR_THREADS / 64) * 2 * SIR_G + 2 * SIR_G + 15 * E + 3 * C) * 4;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
-    auto k = sir_fwd_big_kernel<C, W>;
+    auto k = sir_fwd_big_kernel<C, W, LEAN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -656,13 +670,20 @@ static int sir_big_launch(const SirArgs& a, hipStream_t stream) {
     return ddpm_check_launch("sir_forward");
 }
 
+static bool sir_is_lean(const SirArgs& a) { return !a.raw_e && !a.m_in && !a.m_e && !a.m_d; }
+
 template <int C, int W>
-static int sir_launch(const SirArgs& a, hipStream_t stream) {
+static int sir_big_launch(const SirArgs& a, hipStream_t stream) {
+    return sir_is_lean(a) ? sir_big_launch_as<C, W, true>(a, stream) : sir_big_launch_as<C, W, false>(a, stream);
+}
+
+template <int C, int W, bool LEAN>
+static int sir_launch_as(const SirArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, HW = W * W, IPW = sir_ipw(HW), M = sir_tile_rows(IPW * HW);
     constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) + (SIR_SLOTS * 2 * SIR_G + 2 * IPW * SIR_G + 15 * E + 3 * C) * 4;
     static_assert(IPW == 1 || (Ew<E, M>::NV <= 4 && Ew<C, M>::NV <= 4), "more passes than partial-sum slots");
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
-    auto k = sir_fwd_kernel<C, W>;
+    auto k = sir_fwd_kernel<C, W, LEAN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -673,6 +694,11 @@ static int sir_launch(const SirArgs& a, hipStream_t stream) {
     }
     hipLaunchKernelGGL(k, dim3((a.N + IPW - 1) / IPW), dim3(SIR_THREADS), lds, stream, a);
     return ddpm_check_launch("sir_forward");
+}
+
+template <int C, int W>
+static int sir_launch(const SirArgs& a, hipStream_t stream) {
+    return sir_is_lean(a) ? sir_launch_as<C, W, true>(a, stream) : sir_launch_as<C, W, false>(a, stream);
 }
 
 extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act) {
