@@ -59,6 +59,9 @@ def test_fused_block_inference(dev, n, c, w, act):
     y, saved = run(dev, x, P, act, (None, None, None), 1.0, record=False)
     assert saved is None
     assert_rel(nchw(y), ref["y"], 2.5e-2)
+    # the inference instantiation (no saved tensors, no masks: compiled without those paths) against the recording one
+    y_rec, _ = run(dev, x, P, act, (None, None, None), 1.0, record=True)
+    assert torch.equal(y, y_rec)
 
 
 @pytest.mark.parametrize("n,c,w", SHAPES + FWD_ONLY_SHAPES)
