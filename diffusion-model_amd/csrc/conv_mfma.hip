@@ -498,7 +498,10 @@ extern "C" int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d) {
     if (conv_pick(d, &cfg, &g) < 0) return 0;
     const int bn = 32 * cfg.nt * cfg.wn;
     if (bn % cpg || g.NB != 1 || g.GH % g.TH || g.GW % g.TW) return 0;
-    if ((long long)g.OH * g.OW < 4096) return 0;       // smaller images: whole-image kernels / a cheap statistics pass
+    // only where the GroupNorm that follows takes its many-workgroup path (more than 4096 vectors per image and channel slab,
+    // the rule of groupnorm.hip); smaller problems run the single-pass GroupNorm, which computes its own statistics
+    const int slab = d->Cout % 64 == 0 ? 64 : (d->Cout % 32 == 0 ? 32 : (d->Cout % 16 == 0 ? 16 : 8));
+    if ((long long)g.OH * g.OW * (slab / 8) <= 4096 || g.OH <= 8 || g.OW <= 8) return 0;
     return g.ncls * g.tiles_h * g.tiles_w;
 }
 

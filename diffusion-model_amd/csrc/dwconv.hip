@@ -141,7 +141,9 @@ extern "C" int ddpm_dwconv3x3_stat_parts(int N, int H, int W, int C, int groups)
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || groups <= 0 || groups > 256 || C % groups) return 0;
     const int cpg = C / groups, cvs = C / 8;
     if (cpg < 2 || (cpg & (cpg - 1)) || cvs > 64 || (cvs & (cvs - 1))) return 0;
-    if ((long long)H * W < 4096) return 0;
+    // only where the GroupNorm that follows takes its many-workgroup path (more than 4096 vectors per image and channel slab)
+    const int slab = C % 64 == 0 ? 64 : (C % 32 == 0 ? 32 : (C % 16 == 0 ? 16 : 8));
+    if ((long long)H * W * (slab / 8) <= 4096) return 0;
     const int px = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1);
     const long long per_image = (long long)H * (W / px) * cvs;
     if (per_image % 256 || per_image / 256 > (1 << 20)) return 0;

@@ -433,6 +433,8 @@ def test_conv_img_dgrad_with_fused_groupnorm_backward(dev, kind, n, c0, c, hw, g
     (hip.CONV_1X1, 2, 32, 64, 128, 128, 16, "gelu"),       # 4 channels per group (the UNet's 16 groups at 64 channels)
     (hip.CONV_1X1, 2, 64, 32, 64, 64, 16, "none"),         # 2 channels per group
     (hip.CONV_3X3_S1, 1, 32, 256, 64, 64, 4, "gelu"),      # 64 channels per group
+    (hip.CONV_1X1, 5, 128, 256, 32, 32, 16, "gelu"),       # 32x32 images wide enough for the many-workgroup GroupNorm
+    (hip.CONV_3X3_S1, 3, 64, 64, 32, 32, 16, "silu"),
 ])
 def test_conv_leaves_groupnorm_sums_for_large_images(dev, kind, n, ci, co, h, wd, groups, act):
     """Large images: every output tile of the convolution stores the sums of its results per normalisation group and the

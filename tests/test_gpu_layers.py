@@ -84,7 +84,7 @@ def test_depthwise_fwd_dgrad_wgrad(dev, n, c, h, w_):
 
 
 @pytest.mark.parametrize("n,c,h,w_,groups,act", [(2, 64, 128, 128, 16, "gelu"), (3, 128, 64, 64, 16, "silu"), (1, 32, 64, 96, 16, "gelu"),
-                                                 (2, 256, 64, 64, 4, "relu"), (1, 64, 64, 66, 16, "gelu")])
+                                                 (2, 256, 64, 64, 4, "relu"), (1, 64, 64, 66, 16, "gelu"), (3, 256, 32, 32, 16, "gelu")])
 def test_depthwise_leaves_groupnorm_sums_for_large_images(dev, n, c, h, w_, groups, act):
     """Large images: the depthwise launch stores partial sums of its result per normalisation group, and the GroupNorm that
     follows skips its statistics pass.  Result bit-equal to the plain launch; statistics equal up to fp32 summation order
