@@ -425,7 +425,8 @@ extern "C" int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d);
 
 extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    DDPM_REQUIRE(d && d->in0 && d->w && d->out, "conv: null pointer");
+    DDPM_REQUIRE(d && d->in0 && d->w && (d->out || (d->gn_gamma && d->gn_out && !d->out2 && !d->gn_part)),
+                 "conv: null pointer (the raw output may be omitted only with a fused GroupNorm, whose gn_out is the result)");
     DDPM_REQUIRE(d->kind >= 0 && d->kind < CONV_KIND_COUNT, "conv: unknown kind %d", d->kind);
     DDPM_REQUIRE(d->N > 0 && d->IH > 0 && d->IW > 0, "conv: bad input dims %d x %d x %d", d->N, d->IH, d->IW);
     DDPM_REQUIRE(d->C0 > 0 && d->C0 % 16 == 0 && d->C1 >= 0 && d->C1 % 32 == 0 && (d->C1 == 0 || (d->in1 && d->C0 % 32 == 0)),

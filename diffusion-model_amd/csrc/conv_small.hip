@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)o[j] + (float)rv[j]);
             }
-            if (co0 + c4 + 4 <= a.Cout) {
+            if (!a.out) {
+                // fused GroupNorm at inference: nobody reads the raw result (host-checked: only with gn_out)
+            } else if (co0 + c4 + 4 <= a.Cout) {
                 *(bf16x4*)(a.out + e) = o;
             } else {
                 for (int j = 0; j < a.Cout - co0 - c4; ++j) a.out[e + j] = o[j];

@@ -401,7 +401,7 @@ class UNetEngine:
                 # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
                 raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                                  in_add=None if in_add is None else in_add.v,
-                                                 gn=(gamma, beta, groups, act, None if res is None else res.v))
+                                                 gn=(gamma, beta, groups, act, None if res is None else res.v), keep_raw=tape is not None)
             elif bsc is None and norm is None and res is None and out_mask is None and cout % 8 == 0 and x0.v.shape[1] > 4:
                 # no normalisation: the activated tensor is a second result of the convolution's launch (the pre-activation
                 # stays for the backward pass)

@@ -50,7 +50,7 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
                  res: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, out_scale: float = 1.0,
                  out: Optional[Tensor] = None, f32_nchw: bool = False, out_cs: Optional[int] = None,
                  row0: int = 0, rows: Optional[int] = None, sum_out: Optional[Tensor] = None, gn=None, c0_used: int = 0, act2: Optional[int] = None, gnb=None,
-                 gn_part_groups: int = 0, in_affine=None):
+                 gn_part_groups: int = 0, in_affine=None, keep_raw: bool = True):
     """x0 (and x1): NHWC bf16.  w: packed bf16 [slices][CoutW][C0+C1].  Returns NHWC bf16 [N,OH,OW,out_cs]
     (or NCHW fp32 [N,cout,OH,OW] when f32_nchw).  row0/rows select a sub-range of weight rows (= output channels).
     sum_out (fp32 [N][cout], zeroed by the caller) receives per-image spatial sums of the result before mask/res.
@@ -59,7 +59,8 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     act2: also return act2(result) as a second tensor (the result itself without activation): returns (raw, y).
     c0_used: promise that only the first c0_used (1..4) channels of x0 are non-zero (zero-padded image tensors).
     gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
-    where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone.
+    where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone; keep_raw=False (inference): the raw
+    result is not stored and comes back as None.
     gn_part_groups > 0: returns (raw, part) with part = fp32 [N][groups][tiles][2] per-tile sums (x, x^2) of the result for
     gn_act_forward(stat_part=part), or None where the launch cannot deliver them (small images, odd shapes).
     in_affine = (affine, act): x0 is the raw input of a GroupNorm + activation that has not been applied; affine = fp32
@@ -69,7 +70,10 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     assert x0.dtype == BF16 and x0.is_contiguous() and w.dtype == BF16 and w.is_contiguous()
     assert w.shape[2] == c0 + c1, (tuple(w.shape), c0, c1)
     oh, ow = conv_out_hw(kind, ih, iw)
-    if out is None:
+    no_raw = gn is not None and not keep_raw and out is None and not f32_nchw
+    if no_raw:
+        pass
+    elif out is None:
         if f32_nchw:
             out = torch.empty(n, cout, oh, ow, device=x0.device, dtype=torch.float32)
         else:
@@ -77,7 +81,7 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     d = hip.ConvDesc(kind=kind, N=n, IH=ih, IW=iw, in0=hip.ptr(x0), in1=hip.ptr(x1), C0=c0, C1=c1, in_add=hip.ptr(in_add),
                      in_mask=hip.ptr(in_mask), in_mask_scale=in_scale, w=w.data_ptr() + row0 * w.shape[2] * 2, bias=hip.ptr(bias), out=hip.ptr(out),
                      res=hip.ptr(res), out_mask=hip.ptr(out_mask), out_mask_scale=out_scale, Cout=cout,
-                     CoutW=(w.shape[1] if rows is None else (rows + 31) // 32 * 32), out_cs=(0 if f32_nchw else out.shape[3]),
+                     CoutW=(w.shape[1] if rows is None else (rows + 31) // 32 * 32), out_cs=(0 if f32_nchw else (out_cs or cout) if no_raw else out.shape[3]),
                      w_rows=w.shape[1], act=act, out_mode=(hip.OUT_F32_NCHW if f32_nchw else hip.OUT_BF16_NHWC),
                      sum_out=hip.ptr(sum_out), C0_used=c0_used)
     y = stats = part = None
@@ -110,7 +114,7 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     def cost():
         # every operand once: activations in, weight rows used, bias, epilogue operands, result
         wbytes = _SLICES[kind] * d.CoutW * (c0 + c1) * 2
-        obytes = n * oh * ow * cout * (4 if f32_nchw else 2)
+        obytes = 0 if no_raw else n * oh * ow * cout * (4 if f32_nchw else 2)
         extra = 0 if gnb is None else _nb(gnb[0], gnb[5], gnb[6], gnb[7])
         return (_nb(x0, x1, in_add, in_mask, res, out_mask, sum_out, y, stats, None if gn is None else gn[4]) + wbytes + cout * 4 + obytes + extra,
                 2.0 * n * oh * ow * cout * (c0 + c1) * _TAPS[kind], f"k{kind} {ih}x{iw} {c0}+{c1}->{cout}")

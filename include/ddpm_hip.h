@@ -133,7 +133,8 @@ typedef struct ddpm_conv_desc {
     const void* w;             /* bf16 [slices][w_rows][C0+C1]; rows [0, CoutW) of every slice are used (point w at a later row
                                 * to compute a sub-range of output channels) */
     const float* bias;         /* fp32 [Cout] or NULL */
-    void* out;                 /* NHWC bf16 with channel stride out_cs, or NCHW fp32 (out_mode) */
+    void* out;                 /* NHWC bf16 with channel stride out_cs, or NCHW fp32 (out_mode).  May be NULL with a fused
+                                * GroupNorm (gn_gamma .. gn_out below) at inference: the raw result is then not stored. */
     const void* res;           /* optional NHWC bf16 tensor added in the epilogue (same layout as out) */
     const uint8_t* out_mask;   /* optional dropout keep bits applied to the result before `res` is added */
     float out_mask_scale;

@@ -169,6 +169,11 @@ def test_conv_with_fused_groupnorm(dev, n, ci, c1, co, hw, groups, act, with_res
     assert torch.equal(raw, raw2)
     torch.testing.assert_close(stats, stats2, rtol=1e-4, atol=1e-5)
     assert_rel(y.float().cpu(), y2.float().cpu(), 1e-2)
+    # inference: the raw result is not stored, the normalised one and the statistics are the same bits
+    none, y3, stats3 = ops.conv_forward(hip.CONV_3X3_S1, x0d, pack.pack_fwd(hip.CONV_3X3_S1, w).to(dev), b.to(dev), co, x1=x1d,
+                                        in_add=None if add is None else add.to(dev), keep_raw=False,
+                                        gn=(gamma.to(dev), beta.to(dev), groups, hip.ACT[act], None if res is None else nhwc(res, dev)))
+    assert none is None and torch.equal(y3, y) and torch.equal(stats3, stats)
     assert not ops.conv_gn_fusable(hip.CONV_3X3_S1, torch.empty(2, 64, 64, 32, device=dev, dtype=torch.bfloat16), None, 32, 16)   # image larger than a tile
 
 
@@ -376,6 +381,10 @@ def test_conv_img_fused_groupnorm_forward(dev, kind, n, ci, c1, co, h, groups, a
     assert_rel(raw.float().cpu(), raw2.float().cpu(), 4e-3)              # other summation order: at most one bf16 step
     torch.testing.assert_close(stats, stats2, rtol=2e-3, atol=2e-3)
     assert_rel(y.float().cpu(), y2.float().cpu(), 1.5e-2)
+    # inference: the raw result is not stored, the normalised one and the statistics are the same bits
+    none, y3, stats3 = ops.conv_forward(kind, x0d, wp, b.to(dev), co, keep_raw=False,
+                                        gn=(gamma.to(dev), beta.to(dev), groups, hip.ACT[act], None if res is None else nhwc(res, dev)), **kw)
+    assert none is None and torch.equal(y3, y) and torch.equal(stats3, stats)
 
 
 IMG_BWD_CASES = [
