@@ -206,6 +206,27 @@ def extra_configs(dev, world, dist, barrier, reducer_factory, use_graph):
     return out
 
 
+def _count_gpus_sysfs():
+    """GPUs of this node as the kernel driver lists them (topology nodes with compute units), or None where that listing
+    does not exist.  Reading sysfs opens no device: the launcher parent stays a process that has never touched a GPU."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return None
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if vis is not None and vis.strip() != "":
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh processes of this script, one per GPU, with the
     rendezvous environment torch.distributed reads (the reference spawns one process per GPU the same way,
@@ -215,8 +236,8 @@ def launch_ranks(n: int, argv) -> int:
     import subprocess
     if n < 1:
         sys.exit("bench.py: --gpus must be >= 1")
-    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if "--dry-launch" not in argv and n > have:
+    have = _count_gpus_sysfs()                # (never through the HIP runtime: the parent must not open the GPU before it spawns)
+    if "--dry-launch" not in argv and have is not None and n > have:
         sys.exit(f"bench.py: --gpus {n} but this node has {have} GPU(s)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -237,6 +258,11 @@ def launch_ranks(n: int, argv) -> int:
     for p in live:                           # a failed rank leaves the others waiting in a collective: end exactly those children
         p.kill()
         p.wait()
+    if torch.cuda.is_initialized():          # the launcher's contract: it starts ranks, it never touches a GPU itself
+        print("bench.py: the launcher process initialised the GPU runtime", file=sys.stderr)
+        return rc or 3
+    if "--dry-launch" in argv:
+        print(json.dumps({"launcher": True, "gpu_runtime_initialised": torch.cuda.is_initialized(), "gpus_seen_in_sysfs": have}), flush=True)
     return rc
 
 

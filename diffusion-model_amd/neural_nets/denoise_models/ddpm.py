@@ -107,6 +107,9 @@ class DDPM(nn.Module):
         if wait:
             torch.cuda.synchronize()
         if int(flag[0]) != 0:
+            # (error path only) wait for the device before clearing the words: a checking kernel still in flight could
+            # otherwise write its report between the read above and the clear, and the report would be lost
+            torch.cuda.synchronize()
             bad = int(flag[1])
             flag.zero_()
             raise IndexError(f"{self._t_what}, got {bad}")
@@ -193,6 +196,7 @@ class DDPM(nn.Module):
             T -= 1
             times -= 1
             k += 1
+        self.check_timesteps(wait=True)       # the end of a chain is a natural rendezvous: nothing is reported late from here
         return x
 
     @torch.no_grad()

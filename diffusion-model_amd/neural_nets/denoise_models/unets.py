@@ -164,6 +164,11 @@ class _GraphEntry:
         self.live = None
         self.g_b = self.dout = self.last_flat = None
         self.plist = list(flat_params)
+        self.ptrs = tuple(q.data_ptr() for q in flat_params)          # the graphs bake in every one of these addresses
+        # each parameter's gradient-accumulation node: the autograd engine can be asked, during a backward pass, whether it will
+        # run them (it will not under torch.autograd.grad or backward(inputs=...))
+        self.acc_nodes = [q.view_as(q).grad_fn.next_functions[0][0] for q in flat_params if q.requires_grad] if record else []
+        self.all_need_grad = all(q.requires_grad for q in flat_params)
         repack, eng.always_repack = eng.always_repack, True           # the weight re-layout becomes a node of the graph
         phases, eng.phases = eng.phases, _MODULE_PHASES
         try:
@@ -246,12 +251,14 @@ class _GraphEntry:
         self.pending = False
         fresh = eng.grads.flat_t[:self.total]
         prev, plist = self.last_flat, self.plist
-        if prev is not None and self._accumulating_into(prev, plist):
+        if prev is not None and self._engine_accumulates_all() and self._accumulating_into(prev, plist):
             # a later micro-batch of a gradient-accumulation window: every .grad is still the view of the buffer the previous
-            # call returned.  autograd would now add the 350 new tensors to them one launch each; instead the sum is formed
-            # here by ONE launch and handed over as this call's gradients, with .grad cleared so that autograd adopts the
-            # tensors as they are (hooks on the accumulation step, DistributedDataParallel's among them, run as ever and
-            # find the same .grad they would have found)
+            # call returned, and this backward pass ends in the accumulation step of every parameter (a plain
+            # loss.backward(); under torch.autograd.grad or backward(inputs=subset) the engine hands the gradients to the
+            # caller instead, and they must be this call's alone).  autograd would now add the 350 new tensors one launch
+            # each; instead the sum is formed here by ONE launch and handed over as this call's gradients, with .grad cleared
+            # so that autograd adopts the tensors as they are (hooks on the accumulation step, DistributedDataParallel's
+            # among them, run as ever and find the same .grad they would have found)
             flat = torch.add(prev, fresh)
             for q in plist:
                 q.grad = None
@@ -260,6 +267,16 @@ class _GraphEntry:
         self.last_flat = flat
         return tuple(piece.view(shp) if piece.numel() == n else piece[:n].view(shp)
                      for piece, (n, shp) in zip(flat.split_with_sizes(self.sizes), self.shapes))
+
+    def _engine_accumulates_all(self) -> bool:
+        """True when the running backward pass will execute the gradient-accumulation node of EVERY parameter"""
+        if not self.all_need_grad or not self.acc_nodes:
+            return False
+        try:
+            will = torch._C._will_engine_execute_node
+            return all(will(node) for node in self.acc_nodes)
+        except Exception:                               # (the engine raises for a leaf whose gradient it captures for the caller)
+            return False
 
     def _accumulating_into(self, prev: Tensor, plist) -> bool:
         base, off = prev.data_ptr(), 0
@@ -392,7 +409,14 @@ class BaseUNet(nn.Module):
             return None, None
         key = (tuple(x.shape), x.device.index, self.training, record, flat_params[0].data_ptr(), flat_params[-1].data_ptr(), eng.phases)
         e = self._graphs.get(key)
+        if e is not None and e.ptrs != tuple(q.data_ptr() for q in flat_params):
+            # a parameter in the middle was re-pointed (p.data = ..., a partial weight swap): the captured graphs address the
+            # old storage.  Drop the entry; the shape is captured again on this call.
+            del self._graphs[key]
+            e = None
         if e is None:
+            for k in [k for k, v in self._graphs.items() if k[4:6] != key[4:6]]:
+                del self._graphs[k]                     # entries of a parameter storage that is gone (each holds its activations)
             if self._graph_seen.get(key, 0) < 1:
                 return None, key
             if not x.is_contiguous() or time.dtype != torch.long or time.dim() != 1:

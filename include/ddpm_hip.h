@@ -243,7 +243,9 @@ int ddpm_gn_fold_affine(const float* stat_part, int parts, const float* gamma, c
 int64_t ddpm_gn_scratch_floats(const ddpm_gn_desc* d, int backward);
 /* ddpm_gn_act_forward for callers that cannot allocate or pass a workspace (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arithmetic and results as
- * ddpm_gn_act_forward given a sufficient workspace; d->scratch / d->scratch_floats are ignored: the partial sums of the
+ * ddpm_gn_act_forward given a sufficient workspace and NO producer-side sums; d->scratch / d->scratch_floats and
+ * d->stat_part / d->stat_parts are ignored (the statistics launch always runs: with stat_part the other entry point adds the
+ * producer's sums in another order, so the last bits of its statistics may differ from this one's): the partial sums of the
  * many-workgroup path live in a device array built into the library, ddpm_gn_static_scratch_floats() floats (4 MiB) on every
  * GPU the library runs on, held until the process ends.  A shape that needs more (N * groups * pixel splits * 2 floats) is
  * rejected with an error.  The call allocates nothing.  All calls on one GPU share that array: calls that overlap on one GPU

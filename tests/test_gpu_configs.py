@@ -255,3 +255,79 @@ def test_latent_diffusion_configuration(dev):
     imgs = m.decode(graphs.GraphedSampler(m, 4, (16, 16)).sample())
     torch.cuda.synchronize()
     assert imgs.shape == (4, 3, 64, 64) and torch.isfinite(imgs).all()
+
+
+def test_config3_64x64x3_batch128_pipelined_step_vs_oracle(dev):
+    """BASELINE config 3's per-GPU step exactly as benchmarked (bench.py: extra_configs, train_64x64x3): 64x64x3, batch 128,
+    the pipelined two-stream graph driver, timesteps and noise injected, lr = 0: loss and every parameter gradient against the
+    oracle at that batch (the batch size picks the convolution tiles and the GroupNorm launch shapes, so the small-batch
+    64x64 test does not cover these launches).  Reference: unets.py:100-132,206-240, base_trainer.py:196-235 there."""
+    m, cfg, p = build(dev, 3, "gelu", drop_p=0.0)
+    m.train()
+    n = 128
+    x0 = hash_uniform((n, 3, 64, 64), 131) * 2 - 1
+    t = (hash_uniform((n,), 132) * 120).long().clamp_(0, 119) + 1
+    noise = hash_normal((n, 3, 64, 64), 133)
+    opt = FusedAdam(m.parameters(), lr=0.0)
+    step = graphs.PipelinedTrainStep(m, ELBOLoss("mse"), opt, x0.to(dev), None, phases=4, t=t.to(dev), noise=noise.to(dev))
+    assert step.graphs is not None
+    loss = step.replay().item()
+    loss = step.replay().item()
+    torch.cuda.synchronize()
+    s = O.make_schedule(120, 0.25)
+    loss32, g32 = O.train_step_grads(p, cfg, s, x0, t, noise)
+    with bf16_oracle():
+        loss16, g16 = O.train_step_grads(p, cfg, s, x0, t, noise)
+    assert abs(loss - loss32.item()) < 1e-2 * abs(loss32.item()), (loss, loss32.item())
+    assert abs(loss - loss16.item()) < 5e-3 * abs(loss16.item()), (loss, loss16.item())
+    grad_report(((k, prm.grad) for k, prm in m.named_parameters()), g32, g16, "64x64x3 batch 128, pipelined graphs")
+    for (k, prm), w in zip(m.named_parameters(), p.values()):
+        assert torch.equal(prm.detach().cpu(), w), k
+
+
+def test_config5_four_stage_denoiser_on_64x64x32_latents(dev):
+    """The denoiser of the latent-diffusion configuration at the shape bench.py times (train_ldm / sample_ldm_256x256x3): the
+    full four-stage network, stages [32,64,128,256], latent_dim 512, on 64x64 latents of 32 channels, N = 2: prediction, one
+    reverse step, loss and every gradient against the oracle.  Reference: unets.py:100-132,206-240 there (the same BaseUNet
+    with img_channels = 32)."""
+    m, cfg, p = build(dev, 32, "gelu", drop_p=0.0, head_gain=0.3)
+    m.eval()
+    n = 2
+    x0 = torch.tanh(hash_normal((n, 32, 64, 64), 141))
+    t = torch.tensor([7, 101])
+    noise = hash_normal((n, 32, 64, 64), 142)
+    s = O.make_schedule(120, 0.25)
+    x_t_ref = O.q_sample(s, x0, t, noise)
+    x_t = m.q(x0.to(dev), t.to(dev), noise=noise.to(dev))
+    torch.testing.assert_close(x_t.cpu(), x_t_ref, rtol=1e-6, atol=1e-6)
+    with torch.no_grad():
+        ref = O.unet_forward(p, cfg, x_t_ref, t)
+    pred = m(x_t, t.to(dev))
+    assert l2_err(pred.detach().cpu(), ref) < 5e-2, l2_err(pred.detach().cpu(), ref)
+    z = hash_normal((n, 32, 64, 64), 143)
+    nxt = m.reverse_q(x_t, pred.detach(), t.to(dev), noise=z.to(dev))
+    torch.testing.assert_close(nxt.cpu(), O.reverse_step(s, x_t.cpu(), pred.detach().cpu(), t, z), rtol=1e-5, atol=1e-6)
+    loss32, g32 = O.train_step_grads(p, cfg, s, x0, t, noise)
+    loss = ELBOLoss("mse")(m, t.to(dev), pred, x0.to(dev))["Loss"]
+    assert abs(loss.item() - loss32.item()) < 1e-2 * abs(loss32.item()), (loss.item(), loss32.item())
+    loss.backward()
+    with bf16_oracle():
+        _, g16 = O.train_step_grads(p, cfg, s, x0, t, noise)
+    grad_report(((k, q.grad) for k, q in m.named_parameters()), g32, g16, "64x64x32 latents N=2")
+    # and the pipelined graph driver at the benchmarked batch (32) reproduces the same step's loss on its first two images'
+    # weights: the step runs, is finite and matches the eager loss of the same batch
+    m.train()
+    nb = 32
+    xb = torch.tanh(hash_normal((nb, 32, 64, 64), 144))
+    tb = (hash_uniform((nb,), 145) * 120).long().clamp_(0, 119) + 1
+    zb = hash_normal((nb, 32, 64, 64), 146)
+    opt = FusedAdam(m.parameters(), lr=0.0)
+    step = graphs.PipelinedTrainStep(m, ELBOLoss("mse"), opt, xb.to(dev), None, phases=4, t=tb.to(dev), noise=zb.to(dev))
+    lg = step.replay().item()
+    lg = step.replay().item()
+    torch.cuda.synchronize()
+    with bf16_oracle():
+        lb16, gb16 = O.train_step_grads(p, cfg, s, xb, tb, zb)
+    assert abs(lg - lb16.item()) < 5e-3 * abs(lb16.item()), (lg, lb16.item())
+    errs = sorted(l2_err(q.grad.cpu(), gb16[k]) for k, q in m.named_parameters())
+    assert errs[len(errs) // 2] < 0.07 and errs[-1] < 0.2, (errs[len(errs) // 2], errs[-1])

@@ -778,3 +778,54 @@ def test_module_autograd_path_replays_captured_graphs(dev):
     with torch.no_grad():
         a = m(x0, t); b = m(x0, t); c = m(x0, t)
     assert torch.equal(a, b) and torch.equal(a, c) and len(unet._graphs) == 2
+
+
+def test_captured_backward_under_autograd_grad_and_inputs_subset(dev):
+    """After a plain .backward() whose .grad tensors are still bound, the captured backward pass must hand torch.autograd.grad
+    and backward(inputs=subset) THIS call's gradients only (no one-launch sum with the previous window) and must leave the
+    .grad of parameters outside `inputs` alone, as the eager path (use_graphs = False) does."""
+    m, cfg, p = build(dev, 1, "gelu")
+    m.train()
+    unet = m.model
+    n = 4
+    xa = (hash_uniform((n, 1, 32, 32), 41) * 2 - 1).to(dev)
+    xb = (hash_uniform((n, 1, 32, 32), 42) * 2 - 1).to(dev)
+    t = torch.tensor([2, 33, 90, 119], device=dev)
+    crit = ELBOLoss("mse")
+    params = list(m.parameters())
+    subset = params[:5] + params[-3:]
+    others = [q for q in params if all(q is not s_ for s_ in subset)]
+
+    def run(use_graphs):
+        unet.use_graphs = use_graphs
+        for _ in range(3):                       # eager pass, capture, replay
+            m.zero_grad(set_to_none=True)
+            crit(m, t, m(xa, t), xa)["Loss"].backward()
+        bound = [q.grad.detach().clone() for q in params]                  # .grad stays bound from here on
+        ga = torch.autograd.grad(crit(m, t, m(xb, t), xb)["Loss"], params)
+        after_grad = [q.grad.detach().clone() for q in params]
+        crit(m, t, m(xb, t), xb)["Loss"].backward(inputs=subset)
+        after_subset = [q.grad.detach().clone() for q in params]
+        crit(m, t, m(xb, t), xb)["Loss"].backward()                         # plain accumulation still sums
+        final = [q.grad.detach().clone() for q in params]
+        return bound, [g.detach().clone() for g in ga], after_grad, after_subset, final
+
+    ref = run(False)
+    got = run(True)
+    assert unet._graphs, "the captured path did not engage"
+
+    def close(a, b, k):
+        scale = b.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() <= 2e-4 * scale, k
+
+    for name, r, g in zip(("bound", "autograd.grad", ".grad after autograd.grad", ".grad after inputs=subset", "final"), ref, got):
+        for i, (a, b) in enumerate(zip(g, r)):
+            close(a, b, (name, i))
+    # autograd.grad left every .grad as it was; inputs=subset touched the subset only
+    for a, b in zip(got[2], got[0]):
+        assert torch.equal(a, b)
+    sub_ids = {id(q) for q in subset}
+    for q, a, b in zip(params, got[3], got[0]):
+        if id(q) not in sub_ids:
+            assert torch.equal(a, b)
+    assert len(others) > 0

@@ -152,7 +152,12 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    rows = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["RANK"])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    parent = [d for d in lines if d.get("launcher")]
+    # the parent only starts processes: it must never have initialised the GPU runtime (a process that has, and then spawns
+    # children that open the GPU, is what a shared GPU host forbids)
+    assert len(parent) == 1 and parent[0]["gpu_runtime_initialised"] is False
+    rows = sorted((d for d in lines if "RANK" in d), key=lambda d: d["RANK"])
     assert [d["RANK"] for d in rows] == ["0", "1"] and [d["LOCAL_RANK"] for d in rows] == ["0", "1"]
     assert all(d["WORLD_SIZE"] == "2" and d["MASTER_ADDR"] == "127.0.0.1" for d in rows)
     assert rows[0]["MASTER_PORT"] == rows[1]["MASTER_PORT"]

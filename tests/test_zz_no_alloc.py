@@ -29,9 +29,17 @@ def _both(dev, n, h, w, c, groups, act, seed, with_res):
         stats = torch.full((n, groups, 2), float("nan"), device=dev)
         d = _desc(x, gamma, beta, res, y, stats, groups, hip.ACT[act])
         if static:
-            before = torch.cuda.memory_allocated(dev)
+            # torch's counter only sees torch's caching allocator; the driver's free-memory figure also sees a hipMalloc made
+            # inside the library.  (One untimed call first: the very first launch of a kernel may load its code object.)
             hip.call("ddpm_gn_act_forward_static", C.byref(d), hip.stream())
+            torch.cuda.synchronize()
+            y.fill_(float("nan")); stats.fill_(float("nan"))
+            torch.cuda.synchronize()
+            before, free_before = torch.cuda.memory_allocated(dev), torch.cuda.mem_get_info(dev)[0]
+            hip.call("ddpm_gn_act_forward_static", C.byref(d), hip.stream())
+            torch.cuda.synchronize()
             assert torch.cuda.memory_allocated(dev) == before
+            assert torch.cuda.mem_get_info(dev)[0] == free_before, "the no-allocation entry point changed the device's free memory"
         else:
             need = hip.lib().ddpm_gn_scratch_floats(C.byref(d), 0)
             assert need > 0, "the test shape must take the many-workgroup path (the one that uses the workspace)"
