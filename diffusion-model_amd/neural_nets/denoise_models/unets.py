@@ -167,7 +167,8 @@ class _GraphEntry:
         self.ptrs = tuple(q.data_ptr() for q in flat_params)          # the graphs bake in every one of these addresses
         # each parameter's gradient-accumulation node: the autograd engine can be asked, during a backward pass, whether it will
         # run them (it will not under torch.autograd.grad or backward(inputs=...))
-        self.acc_nodes = [q.view_as(q).grad_fn.next_functions[0][0] for q in flat_params if q.requires_grad] if record else []
+        with torch.enable_grad():                       # (grad mode is off inside an autograd Function's forward)
+            self.acc_nodes = [q.view_as(q).grad_fn.next_functions[0][0] for q in flat_params if q.requires_grad] if record else []
         self.all_need_grad = all(q.requires_grad for q in flat_params)
         repack, eng.always_repack = eng.always_repack, True           # the weight re-layout becomes a node of the graph
         phases, eng.phases = eng.phases, _MODULE_PHASES

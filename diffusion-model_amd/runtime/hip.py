@@ -106,7 +106,20 @@ class WgradDesc(C.Structure):
     ]
 
 
+class LdsOp(C.Structure):
+    _fields_ = [("type", _i), ("kind", _i), ("src_off", _i), ("src_stride", _i), ("dst_off", _i), ("dst_stride", _i), ("aux_off", _i),
+                ("aux_stride", _i), ("w_in", _i), ("w_out", _i), ("cin", _i), ("cout", _i), ("col0", _i), ("groups", _i), ("act", _i),
+                ("gstride", _i), ("gcol0", _i), ("pad0", _i), ("eps", _f), ("mscale", _f), ("p", _vp * 6)]
+
+
+LOP_END, LOP_LOAD, LOP_STORE, LOP_CONV, LOP_GN, LOP_DW, LOP_ADDT, LOP_MASK = range(8)
+
 _PROTOS = {
+    "ddpm_unet_lds_arena0": ([], _i),
+    "ddpm_unet_lds_reduce_bytes": ([], _i),
+    "ddpm_unet_lds_max_bytes": ([], _i),
+    "ddpm_unet_lds_check": ([_vp, _i, _i], C.c_longlong),
+    "ddpm_unet_lds_run": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_abi_version": ([], _i),
     "ddpm_q_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _u32, _vp], _i),
     "ddpm_reverse_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _u32, _i, C.c_uint64, _vp], _i),

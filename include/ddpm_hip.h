@@ -400,6 +400,43 @@ typedef struct ddpm_sir_bwd_desc {
 int ddpm_sir_workgroups(int HW, int N);
 int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t stream);
 
+/* ---- the low-resolution stages of the UNet as ONE launch, activations resident in LDS (unet_lds.hip) --------------------
+ * A workgroup carries `ipw` images through a program of layers: BaseUNetEncoder / BaseUNetDecoder.forward between two
+ * points of the network (unets.py:127-131,230-237), i.e. DownBlock / UpBlock (constituent_blocks.py:135-147,227-243) and
+ * SeparableInvertResidual (conv_block.py:132-136) bodies, layer by layer, without leaving the CU.  The program is a table
+ * of operations on tiles of an LDS arena laid out by the caller: a tile = (byte offset, row stride in bytes), rows = the
+ * pixels of the workgroup's images in image-major order, bf16 channels.  The arena's first ddpm_unet_lds_arena0() bytes
+ * belong to the kernel.  Every pointer inside an operation is a DEVICE pointer.
+ *   LOAD   p[0] = NHWC bf16 tensor (gstride channels per pixel, first channel gcol0) -> columns [col0, col0+cout) of dst
+ *   STORE  columns [col0, col0+cout) of src -> p[0] (same addressing)
+ *   CONV   kind = DDPM_CONV_3X3_S1 / _3X3_S2 / _1X1 / DDPM_CONVT_2X2_S2: src tile (w_in x w_in images, cin channels) ->
+ *          columns [col0, col0+cout) of dst (w_out x w_out), raw result + bias rounded to bf16; p[0] = bf16 weights in the
+ *          forward weight-copy layout [taps][gstride][cin], p[1] = fp32 bias or NULL; aux_off = ddpm_unet_lds_reduce_bytes()
+ *          bytes of scratch when the layer has fewer than 8 output tiles of 32 x 32
+ *   GN     in place on columns [col0, col0+cout) of dst: y = [aux tile +] mask * act(GroupNorm_groups(x) * p[0] + p[1]);
+ *          act = 0 or the activation the launch was built for; p[2] = keep bits (1 per element, element index
+ *          (image * pixels + pixel) * cout + channel) or NULL, scaled by mscale; aux_stride != 0: residual tile;
+ *          training records: p[3] = raw input bf16 [N][pixels][cout], p[4] = result, p[5] = statistics fp32 [N][groups][2]
+ *   DW     depthwise 3x3 + bias in place on dst: p[0] = fp32 [9][cout], p[1] = fp32 [cout]
+ *   ADDT   columns [col0, col0+cout) of dst += p[0] (fp32 [N][cout]) broadcast over the pixels (unets.py:128,237)
+ *   MASK   dst = src * keep bits of p[0] * mscale (the dropout on a block input, conv_block.py:57-58)
+ * ddpm_unet_lds_check validates a HOST copy of the table and returns the LDS bytes the program needs (< 0: error);
+ * ddpm_unet_lds_run validates the host copy, then launches ceil(N / ipw) workgroups that read the DEVICE copy. */
+enum { DDPM_LOP_END = 0, DDPM_LOP_LOAD = 1, DDPM_LOP_STORE = 2, DDPM_LOP_CONV = 3, DDPM_LOP_GN = 4, DDPM_LOP_DW = 5, DDPM_LOP_ADDT = 6,
+       DDPM_LOP_MASK = 7 };
+typedef struct ddpm_lds_op {
+    int32_t type, kind;
+    int32_t src_off, src_stride, dst_off, dst_stride, aux_off, aux_stride;
+    int32_t w_in, w_out, cin, cout, col0, groups, act, gstride, gcol0, pad0;
+    float eps, mscale;
+    const void* p[6];
+} ddpm_lds_op;
+int ddpm_unet_lds_arena0(void);
+int ddpm_unet_lds_reduce_bytes(void);
+int ddpm_unet_lds_max_bytes(void);
+long long ddpm_unet_lds_check(const ddpm_lds_op* ops_host, int nops, int ipw);
+int ddpm_unet_lds_run(const ddpm_lds_op* ops_dev, const ddpm_lds_op* ops_host, int nops, int N, int ipw, int act, ddpm_stream_t stream);
+
 /* ---- all time-embedding MLPs of the network in one launch (embed_mlp.hip) --------------------------------------
  * EmbedBlock (constituent_blocks.py:282-328): out_i = Linear_1(act(Linear_0(sin))) for every stage i, sin = the
  * sinusoidal embedding [N][t_dim] bf16 (ddpm_time_embedding), t_dim = 32.  Width C[i], hidden width 2*C[i].
