@@ -24,6 +24,7 @@ import torch
 from torch import Tensor
 
 from . import hip, ops, pack
+from .lds_program import LdsOutOfSpace, LdsProgram
 from .params import GradStore, WeightCache, conv_dims
 
 _LOADER_ACTS = (0, hip.ACT["gelu"], hip.ACT["silu"])   # activations the convolution loader can apply (normalise-on-load)
@@ -181,6 +182,11 @@ class UNetEngine:
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.conv_stats = os.environ.get("DDPM_CONV_STATS", "1") != "0"   # large images: GroupNorm sums from the convolution's tiles
         self.norm_on_load = os.environ.get("DDPM_NORM_ON_LOAD", "1") != "0"  # inference, large images: GroupNorm + act in the consumer's loader
+        # the low-resolution stages as one launch with the activations resident in LDS (csrc/unet_lds.hip) where the shapes fit
+        self.use_lds = os.environ.get("DDPM_LDS", "1") != "0"
+        self.lds_ipw = int(os.environ.get("DDPM_LDS_IPW", "1"))      # images per workgroup of that launch
+        self._lds_s0: Dict[Tuple, Optional[int]] = {}
+        self._lds_pin: Dict[str, list] = {}
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
         self.phases = 1                 # backward in 1, 2 (decoder | encoder), 4 (each halved at its middle stage), 5 (the last
                                         # of those cut again after the first encoder convolution) or, for any larger value,
@@ -878,12 +884,20 @@ class UNetEngine:
         skips: List[Var] = []
         marks: List[int] = []                           # tape positions where a backward phase ends (forward order)
         cuts = self._phase_cuts(nst)
-        for i in range(nst):
+
+        def temb_of(pre: str, i: int) -> Var:
+            return temb_vars.get(f"{pre}t_embeddings.{i}.") or embed(f"{pre}t_embeddings.{i}.", sin_v)
+
+        # inference: everything from the first encoder stage whose images fit the LDS of a workgroup down to the latent and up
+        # again to the same depth is ONE launch (the activations never leave the CU); the stages above it run layer by layer
+        s0 = self._lds_first_stage(P, wc, h, w, z.v.shape[3]) if (tape is None and taps is None) else None
+        nenc = nst if s0 is None else s0
+        for i in range(nenc):
             b = f"{e}layers.{i}.layers."
             if tape is not None and f"enc{i}" in cuts:
                 marks.append(len(tape))
             stage_seg[i] = len(marks)
-            temb = temb_vars.get(f"{e}t_embeddings.{i}.") or embed(f"{e}t_embeddings.{i}.", sin_v)
+            temb = temb_of(e, i)
             a = conv_unit(b + "0.0", z, in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
             if tape is not None and i == 0 and "enc0b" in cuts:
                 marks.append(len(tape))
@@ -896,25 +910,31 @@ class UNetEngine:
             z = conv_unit(f"{b}{k + 2}.0", a, norm=f"{b}{k + 2}.1", groups=sp.groups, act=sp.act)
             skips.append(z)
             tap(f"enc.stage{i}", z.v)
-        z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
-        tap("enc.latent", z.v)
-        if tape is not None and "dec" in cuts:          # everything recorded from here on is the decoder
-            marks.append(len(tape))
-        z = conv_unit(d + "decoder_input_layers.0", z, norm=d + "decoder_input_layers.1", groups=sp.groups, act=sp.act)
-        tap("dec.input", z.v)
-        for i in range(nst):
-            b = f"{d}layers.{i}.layers."
-            if tape is not None and f"dec{i}" in cuts:
+        jfirst = 0
+        if s0 is not None:
+            jfirst = nst - 1 - s0                        # the decoder stage whose transposed-convolution unit ends the launch
+            a = Var(self._lds_run(P, wc, z.v, lambda pre, i: temb_of(pre, i).v, n, s0))
+        else:
+            z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
+            tap("enc.latent", z.v)
+            if tape is not None and "dec" in cuts:          # everything recorded from here on is the decoder
                 marks.append(len(tape))
-            stage_seg[nst + i] = len(marks)
-            temb = temb_vars.get(f"{d}t_embeddings.{i}.") or embed(f"{d}t_embeddings.{i}.", sin_v)
-            a = conv_unit(b + "0.0", z, x1=skips[nst - 1 - i], in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
+            z = conv_unit(d + "decoder_input_layers.0", z, norm=d + "decoder_input_layers.1", groups=sp.groups, act=sp.act)
+            tap("dec.input", z.v)
+        for i in range(jfirst, nst):
+            b = f"{d}layers.{i}.layers."
             k = 1
-            if nst - 1 - i in sp.attn_stages:
-                a = c_.attn_module(b + "1.", a, None, sp.attn_depth, sp.attn_heads)
-                k = 2
-            a = sir(f"{b}{k}.", a)
-            a = conv_unit(f"{b}{k + 1}.0", a, norm=f"{b}{k + 1}.1", groups=sp.groups, act=sp.act)
+            if s0 is None or i > jfirst:
+                if tape is not None and f"dec{i}" in cuts:
+                    marks.append(len(tape))
+                stage_seg[nst + i] = len(marks)
+                temb = temb_of(d, i)
+                a = conv_unit(b + "0.0", z, x1=skips[nst - 1 - i], in_add=temb, norm=b + "0.1", groups=sp.groups, act=sp.act)
+                if nst - 1 - i in sp.attn_stages:
+                    a = c_.attn_module(b + "1.", a, None, sp.attn_depth, sp.attn_heads)
+                    k = 2
+                a = sir(f"{b}{k}.", a)
+                a = conv_unit(f"{b}{k + 1}.0", a, norm=f"{b}{k + 1}.1", groups=sp.groups, act=sp.act)
             a = sir(f"{b}{k + 2}.", a)
             z = sir(f"{b}{k + 3}.", a)
             tap(f"dec.stage{i}", z.v)
@@ -975,6 +995,170 @@ class UNetEngine:
         flush(0, True)
         tape.clear()
         return [v.g for v in in_vars], self.grads.unpack()
+
+    # ------------------------------------------------------------------------------------------ LDS-resident stages
+    def _stage_table(self, arr, nbytes: int, dev, slot: str) -> Tensor:
+        """Copy a host table (ctypes array) to a fresh device buffer through pinned memory on the launch stream.  Under graph
+        capture the copy becomes a node that re-reads the pinned buffer at every replay, so that buffer is taken from the
+        ones set aside by earlier eager passes and never reused afterwards."""
+        import ctypes as C
+        pinned = lambda: torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)                # noqa: E731
+        st = self._lds_pin.setdefault(slot, [None, None])                                         # [eager buffer, its last copy's event]
+        if torch.cuda.is_current_stream_capturing():
+            fit = sorted((b.numel(), i) for i, b in enumerate(self._pin_spares) if b.numel() >= nbytes)
+            if not fit:
+                raise RuntimeError("no pinned staging buffer set aside for this capture: run the pass eagerly at least once before capturing it")
+            host = self._pin_spares.pop(fit[0][1])
+            self._pin_captured.append(host)
+        else:
+            if st[0] is None or st[0].numel() < nbytes:
+                st[0] = pinned()
+            elif st[1] is not None:
+                st[1].synchronize()                    # the previous launch's copy must have read the buffer
+            host = st[0]
+            if len(self._pin_spares) < 64:
+                self._pin_spares.append(pinned())
+        C.memmove(host.data_ptr(), arr, nbytes)
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        blob.copy_(host[:nbytes], non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            st[1] = torch.cuda.Event()
+            st[1].record()
+        return blob
+
+    def _lds_build(self, P, wc, z: Tensor, temb: Callable[[str, int], Tensor], n: int, s0: int, ipw: int, new: Callable[..., Tensor]):
+        """The program of the UNet between the input of encoder stage s0 (z: NHWC bf16) and the output of the transposed
+        convolution unit of the decoder stage at the same depth (unets.py:127-131,230-237; constituent_blocks.py:135-147,
+        227-243; conv_block.py:132-136 there), inference form.  -> (program, output tensor, algorithmic bytes, flops)."""
+        sp = self.spec
+        nst, G, act = len(sp.stages), sp.groups, sp.act
+        e, d = "encoder.", "decoder."
+        prog = LdsProgram(ipw, act)
+        cost = [2 * z.numel(), 0.0]                    # bytes (activations in / out, skips twice, weights once), flops
+
+        def conv(kind, src, dst, name, cin, cout, col0=0):
+            wt = wc.fwd[name]
+            prog.conv(kind, src, dst, wt, P.get(name + ".bias"), cin, cout, col0)
+            rows = n * (src.w * src.w if kind == KT22 else dst.w * dst.w)
+            cost[0] += 2 * wt.numel()
+            cost[1] += 2.0 * rows * cin * cout * (9 if kind in (K33, K33S2) else 4 if kind == KT22 else 1)
+
+        def gn(t, norm, groups, a, ch, res=None):
+            prog.gn(t, P[norm + ".weight"], P[norm + ".bias"], groups, a, ch, 0, res)
+
+        def sir(x, pre, c, wide=0):
+            ech = P[pre + "depthwise.1.bias"].shape[0]
+            et = prog.tile(x.w, ech)
+            conv(K11, x, et, pre + "expansion.1", c, ech)
+            gn(et, pre + "expansion.2", G, act, ech)
+            prog.dw(et, wc.dw[pre + "depthwise.1"], P[pre + "depthwise.1.bias"], ech)
+            gn(et, pre + "depthwise.2", G, act, ech)
+            x2 = prog.tile(x.w, c + wide)
+            conv(K11, et, x2, pre + "projection.1", ech, c)
+            prog.free(et)
+            gn(x2, pre + "projection.2", G, 0, c, res=x)
+            prog.free(x)
+            return x2
+
+        cin, w = z.shape[3], z.shape[1]
+        tin = prog.tile(w, cin)
+        prog.load(tin, z)
+        skips = {}
+        for i in range(s0, nst):
+            c, b = sp.stages[i], f"{e}layers.{i}.layers."
+            prog.addt(tin, temb(e, i), cin)
+            w //= 2
+            x = prog.tile(w, c)
+            conv(K33S2, tin, x, b + "0.0", cin, c)
+            prog.free(tin)
+            gn(x, b + "0.1", G, act, c)
+            x = sir(x, b + "1.", c)
+            x = sir(x, b + "2.", c)
+            y = prog.tile(w, c)
+            conv(K33, x, y, b + "3.0", c, c)
+            prog.free(x)
+            gn(y, b + "3.1", G, act, c)
+            skips[i] = new(n, w, w, c)
+            prog.store(y, skips[i])
+            cost[0] += 4 * skips[i].numel()
+            tin, cin = y, c
+        L = sp.latent_dim
+        y = prog.tile(w, L)
+        conv(K33, tin, y, e + "latent_layers.0", cin, L)
+        prog.free(tin)
+        gn(y, e + "latent_layers.1", sp.latent_groups, act, L)
+        rs = sp.stages[::-1]
+        outs = rs[1:] + [rs[-1]]
+        zt = prog.tile(w, 2 * rs[0])
+        conv(K33, y, zt, d + "decoder_input_layers.0", L, rs[0])
+        prog.free(y)
+        gn(zt, d + "decoder_input_layers.1", G, act, rs[0])
+        out = None
+        for j in range(nst - s0):
+            i, ci, co, b = nst - 1 - j, rs[j], outs[j], f"{d}layers.{j}.layers."
+            prog.addt(zt, temb(d, j), ci)
+            prog.load(zt, skips[i], col0=ci)
+            a = prog.tile(w, ci)
+            conv(K33, zt, a, b + "0.0", 2 * ci, ci)
+            prog.free(zt)
+            gn(a, b + "0.1", G, act, ci)
+            a = sir(a, b + "1.", ci)
+            w *= 2
+            up = prog.tile(w, co)
+            conv(KT22, a, up, b + "2.0", ci, co)
+            prog.free(a)
+            gn(up, b + "2.1", G, act, co)
+            if j == nst - 1 - s0:
+                out = new(n, w, w, co)
+                prog.store(up, out)
+                cost[0] += 2 * out.numel()
+                break
+            a = sir(up, b + "3.", co)
+            zt = sir(a, b + "4.", co, wide=co)
+        return prog, out, cost[0], cost[1]
+
+    def _lds_first_stage(self, P, wc, h: int, w: int, c_stem: int) -> Optional[int]:
+        """The first encoder stage from which the rest of the U fits the LDS of one workgroup (None: no stage does, or the
+        network has a feature the LDS kernel lacks).  Found by laying the program out for one workgroup's images on
+        placeholder tensors; cached per input size."""
+        sp = self.spec
+        key = (h, w, self.lds_ipw)
+        if key in self._lds_s0:
+            return self._lds_s0[key]
+        ok = (self.use_lds and not sp.attn_stages and not sp.act_scalar and sp.act in (hip.ACT["gelu"], hip.ACT["silu"], hip.ACT["relu"])
+              and h == w and (h & (h - 1)) == 0 and sp.groups >= 8 and (sp.groups & (sp.groups - 1)) == 0
+              and all((c & (c - 1)) == 0 for c in sp.stages + [sp.latent_dim]) and sp.expand == 2)
+        found = None
+        if ok:
+            ipw, nst = self.lds_ipw, len(sp.stages)
+            cpu = lambda *shape: torch.empty(*shape, dtype=BF16)                                 # noqa: E731
+            for s0 in range(nst):
+                cin = c_stem if s0 == 0 else sp.stages[s0 - 1]
+                side = h >> s0
+                if side >> (nst - s0) < 1 or side > 64:
+                    continue
+                try:
+                    widths = {}
+                    prog, _, _, _ = self._lds_build(P, wc, cpu(ipw, side, side, cin),
+                                                    lambda pre, i, widths=widths: torch.empty(ipw, P[f"{pre}t_embeddings.{i}.layers.2.bias"].shape[0]),
+                                                    ipw, s0, ipw, cpu)
+                    prog.check()
+                    found = s0
+                    break
+                except (LdsOutOfSpace, RuntimeError, AssertionError):
+                    continue
+        self._lds_s0[key] = found
+        return found
+
+    def _lds_run(self, P, wc, z: Tensor, temb: Callable[[str, int], Tensor], n: int, s0: int) -> Tensor:
+        dev = z.device
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=BF16)                        # noqa: E731
+        prog, out, nbytes, flops = self._lds_build(P, wc, z, temb, n, s0, self.lds_ipw, new)
+        arr, size = prog.table()
+        blob = self._stage_table(arr, size, dev, "lds")
+        ops._launch("unet_lds_kernel", lambda: (nbytes, flops, f"{len(arr) - 1} ops from stage {s0}"),
+                    lambda: hip.call("ddpm_unet_lds_run", blob.data_ptr(), arr, len(arr), n, prog.ipw, prog.act, hip.stream()))
+        return out
 
     def _launch_wgrad_group(self, pending, dev) -> None:
         """All deferred dense weight gradients in at most five launches.  The problem tables are built on the host,
