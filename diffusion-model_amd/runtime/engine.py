@@ -184,7 +184,8 @@ class UNetEngine:
         self.norm_on_load = os.environ.get("DDPM_NORM_ON_LOAD", "1") != "0"  # inference, large images: GroupNorm + act in the consumer's loader
         # the low-resolution stages as one launch with the activations resident in LDS (csrc/unet_lds.hip) where the shapes fit
         self.use_lds = os.environ.get("DDPM_LDS", "1") != "0"
-        self.lds_ipw = int(os.environ.get("DDPM_LDS_IPW", "1"))      # images per workgroup of that launch
+        self.lds_ipw = int(os.environ.get("DDPM_LDS_IPW", "1"))      # images per workgroup of that launch ...
+        self.lds_ipw_deep = int(os.environ.get("DDPM_LDS_IPW_DEEP", "8"))   # ... and of the launch that holds the deepest stages
         self._lds_s0: Dict[Tuple, Optional[int]] = {}
         self._lds_pin: Dict[str, list] = {}
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
@@ -890,7 +891,8 @@ class UNetEngine:
 
         # inference: everything from the first encoder stage whose images fit the LDS of a workgroup down to the latent and up
         # again to the same depth is ONE launch (the activations never leave the CU); the stages above it run layer by layer
-        s0 = self._lds_first_stage(P, wc, h, w, z.v.shape[3]) if (tape is None and taps is None) else None
+        plan = self._lds_first_stage(P, wc, h, w, z.v.shape[3]) if (tape is None and taps is None) else None
+        s0 = None if plan is None else plan[0]
         nenc = nst if s0 is None else s0
         for i in range(nenc):
             b = f"{e}layers.{i}.layers."
@@ -913,7 +915,7 @@ class UNetEngine:
         jfirst = 0
         if s0 is not None:
             jfirst = nst - 1 - s0                        # the decoder stage whose transposed-convolution unit ends the launch
-            a = Var(self._lds_run(P, wc, z.v, lambda pre, i: temb_of(pre, i).v, n, s0))
+            a = Var(self._lds_run(P, wc, z.v, lambda pre, i: temb_of(pre, i).v, n, plan))
         else:
             z = conv_unit(e + "latent_layers.0", z, norm=e + "latent_layers.1", groups=sp.latent_groups, act=sp.act)
             tap("enc.latent", z.v)
@@ -1026,27 +1028,50 @@ class UNetEngine:
             st[1].record()
         return blob
 
-    def _lds_build(self, P, wc, z: Tensor, temb: Callable[[str, int], Tensor], n: int, s0: int, ipw: int, new: Callable[..., Tensor]):
-        """The program of the UNet between the input of encoder stage s0 (z: NHWC bf16) and the output of the transposed
+    def _lds_build(self, P, wc, z: Tensor, temb: Callable[[str, int], Tensor], n: int, s0: int, s1: int, ipw_top: int, ipw_bot: int,
+                   new: Callable[..., Tensor]):
+        """The programs of the UNet between the input of encoder stage s0 (z: NHWC bf16) and the output of the transposed
         convolution unit of the decoder stage at the same depth (unets.py:127-131,230-237; constituent_blocks.py:135-147,
-        227-243; conv_block.py:132-136 there), inference form.  -> (program, output tensor, algorithmic bytes, flops)."""
+        227-243; conv_block.py:132-136 there), inference form.  Up to three launches: encoder stages [s0, s1) with ipw_top
+        images per workgroup; stages [s1, last], the latent and decoder-input layers and the decoder up to the transposed
+        convolution of the stage at depth s1 with ipw_bot (the deep stages hold nine tenths of the weights and a few KB of
+        activations per image: a workgroup that streams them once for many images is what they want); the rest of the decoder
+        with ipw_top again.  s1 == s0: one launch.  -> ([(program, cost bytes, flops)], output tensor)."""
         sp = self.spec
         nst, G, act = len(sp.stages), sp.groups, sp.act
         e, d = "encoder.", "decoder."
-        prog = LdsProgram(ipw, act)
-        cost = [2 * z.numel(), 0.0]                    # bytes (activations in / out, skips twice, weights once), flops
+        rs = sp.stages[::-1]
+        outs = rs[1:] + [rs[-1]]
+        progs = []
+        cur = {}
+
+        def begin(ipw):
+            cur["p"], cur["cost"] = LdsProgram(ipw, act), [0, 0.0]
+            return cur["p"]
+
+        def end():
+            progs.append((cur["p"], cur["cost"][0], cur["cost"][1]))
 
         def conv(kind, src, dst, name, cin, cout, col0=0):
             wt = wc.fwd[name]
-            prog.conv(kind, src, dst, wt, P.get(name + ".bias"), cin, cout, col0)
+            cur["p"].conv(kind, src, dst, wt, P.get(name + ".bias"), cin, cout, col0)
             rows = n * (src.w * src.w if kind == KT22 else dst.w * dst.w)
-            cost[0] += 2 * wt.numel()
-            cost[1] += 2.0 * rows * cin * cout * (9 if kind in (K33, K33S2) else 4 if kind == KT22 else 1)
+            cur["cost"][0] += 2 * wt.numel()
+            cur["cost"][1] += 2.0 * rows * cin * cout * (9 if kind in (K33, K33S2) else 4 if kind == KT22 else 1)
 
         def gn(t, norm, groups, a, ch, res=None):
-            prog.gn(t, P[norm + ".weight"], P[norm + ".bias"], groups, a, ch, 0, res)
+            cur["p"].gn(t, P[norm + ".weight"], P[norm + ".bias"], groups, a, ch, 0, res)
+
+        def load(t, g, col0=0):
+            cur["p"].load(t, g, col0=col0)
+            cur["cost"][0] += 2 * g.numel()
+
+        def store(t, g):
+            cur["p"].store(t, g)
+            cur["cost"][0] += 2 * g.numel()
 
         def sir(x, pre, c, wide=0):
+            prog = cur["p"]
             ech = P[pre + "depthwise.1.bias"].shape[0]
             et = prog.tile(x.w, ech)
             conv(K11, x, et, pre + "expansion.1", c, ech)
@@ -1060,69 +1085,103 @@ class UNetEngine:
             prog.free(x)
             return x2
 
-        cin, w = z.shape[3], z.shape[1]
-        tin = prog.tile(w, cin)
-        prog.load(tin, z)
         skips = {}
-        for i in range(s0, nst):
+
+        def enc_stage(tin, cin, i):
+            prog = cur["p"]
             c, b = sp.stages[i], f"{e}layers.{i}.layers."
             prog.addt(tin, temb(e, i), cin)
-            w //= 2
-            x = prog.tile(w, c)
+            x = prog.tile(tin.w // 2, c)
             conv(K33S2, tin, x, b + "0.0", cin, c)
             prog.free(tin)
             gn(x, b + "0.1", G, act, c)
             x = sir(x, b + "1.", c)
             x = sir(x, b + "2.", c)
-            y = prog.tile(w, c)
+            y = prog.tile(x.w, c)
             conv(K33, x, y, b + "3.0", c, c)
             prog.free(x)
             gn(y, b + "3.1", G, act, c)
-            skips[i] = new(n, w, w, c)
-            prog.store(y, skips[i])
-            cost[0] += 4 * skips[i].numel()
-            tin, cin = y, c
-        L = sp.latent_dim
-        y = prog.tile(w, L)
-        conv(K33, tin, y, e + "latent_layers.0", cin, L)
-        prog.free(tin)
-        gn(y, e + "latent_layers.1", sp.latent_groups, act, L)
-        rs = sp.stages[::-1]
-        outs = rs[1:] + [rs[-1]]
-        zt = prog.tile(w, 2 * rs[0])
-        conv(K33, y, zt, d + "decoder_input_layers.0", L, rs[0])
-        prog.free(y)
-        gn(zt, d + "decoder_input_layers.1", G, act, rs[0])
-        out = None
-        for j in range(nst - s0):
+            skips[i] = new(n, y.w, y.w, c)
+            store(y, skips[i])
+            return y, c
+
+        def dec_first_half(zt, j):
+            """decoder stage j up to its transposed-convolution unit; zt: wide tile with Z in its first columns"""
+            prog = cur["p"]
             i, ci, co, b = nst - 1 - j, rs[j], outs[j], f"{d}layers.{j}.layers."
             prog.addt(zt, temb(d, j), ci)
-            prog.load(zt, skips[i], col0=ci)
-            a = prog.tile(w, ci)
+            load(zt, skips[i], col0=ci)
+            a = prog.tile(zt.w, ci)
             conv(K33, zt, a, b + "0.0", 2 * ci, ci)
             prog.free(zt)
             gn(a, b + "0.1", G, act, ci)
             a = sir(a, b + "1.", ci)
-            w *= 2
-            up = prog.tile(w, co)
+            up = prog.tile(2 * a.w, co)
             conv(KT22, a, up, b + "2.0", ci, co)
             prog.free(a)
             gn(up, b + "2.1", G, act, co)
-            if j == nst - 1 - s0:
-                out = new(n, w, w, co)
-                prog.store(up, out)
-                cost[0] += 2 * out.numel()
-                break
-            a = sir(up, b + "3.", co)
-            zt = sir(a, b + "4.", co, wide=co)
-        return prog, out, cost[0], cost[1]
+            return up
 
-    def _lds_first_stage(self, P, wc, h: int, w: int, c_stem: int) -> Optional[int]:
-        """The first encoder stage from which the rest of the U fits the LDS of one workgroup (None: no stage does, or the
-        network has a feature the LDS kernel lacks).  Found by laying the program out for one workgroup's images on
-        placeholder tensors; cached per input size."""
+        def dec_second_half(up, j):
+            co, b = outs[j], f"{d}layers.{j}.layers."
+            a = sir(up, b + "3.", co)
+            return sir(a, b + "4.", co, wide=co)          # the next stage concatenates its skip behind these columns
+
+        def hand_over(t, ch):
+            g = new(n, t.w, t.w, ch)
+            store(t, g)
+            end()
+            return g
+
+        jlast = nst - 1 - s0                            # the decoder stage whose transposed-convolution unit ends the last launch
+        jcut = nst - 1 - s1                             # ... the middle launch
+        g, cin = z, z.shape[3]
+        if s1 > s0:
+            prog = begin(ipw_top)
+            tin = prog.tile(g.shape[1], cin)
+            load(tin, g)
+            for i in range(s0, s1):
+                tin, cin = enc_stage(tin, cin, i)
+            end()                                       # (its last skip is the middle launch's input)
+            g = skips[s1 - 1]
+        prog = begin(ipw_bot)
+        tin = prog.tile(g.shape[1], cin)
+        load(tin, g)
+        for i in range(s1, nst):
+            tin, cin = enc_stage(tin, cin, i)
+        L = sp.latent_dim
+        y = prog.tile(tin.w, L)
+        conv(K33, tin, y, e + "latent_layers.0", cin, L)
+        prog.free(tin)
+        gn(y, e + "latent_layers.1", sp.latent_groups, act, L)
+        zt = prog.tile(y.w, 2 * rs[0])
+        conv(K33, y, zt, d + "decoder_input_layers.0", L, rs[0])
+        prog.free(y)
+        gn(zt, d + "decoder_input_layers.1", G, act, rs[0])
+        for j in range(jcut + 1):
+            up = dec_first_half(zt, j)
+            if j < jcut:
+                zt = dec_second_half(up, j)
+        out = hand_over(up, outs[jcut])
+        if s1 > s0:
+            prog = begin(ipw_top)
+            up = prog.tile(out.shape[1], outs[jcut])
+            load(up, out)
+            zt = dec_second_half(up, jcut)
+            for j in range(jcut + 1, jlast + 1):
+                up = dec_first_half(zt, j)
+                if j < jlast:
+                    zt = dec_second_half(up, j)
+            out = hand_over(up, outs[jlast])
+        return progs, out
+
+    def _lds_first_stage(self, P, wc, h: int, w: int, c_stem: int):
+        """(s0, s1, images per workgroup of the deep launch): s0 = the first encoder stage from which the rest of the U fits
+        the LDS of one workgroup, s1 >= s0 = the first stage that still fits with several images per workgroup.  None: no
+        stage fits, or the network has a feature the LDS kernel lacks.  Found by laying the programs out for one workgroup's
+        images on placeholder tensors; cached per input size."""
         sp = self.spec
-        key = (h, w, self.lds_ipw)
+        key = (h, w, self.lds_ipw, self.lds_ipw_deep)
         if key in self._lds_s0:
             return self._lds_s0[key]
         ok = (self.use_lds and not sp.attn_stages and not sp.act_scalar and sp.act in (hip.ACT["gelu"], hip.ACT["silu"], hip.ACT["relu"])
@@ -1130,34 +1189,49 @@ class UNetEngine:
               and all((c & (c - 1)) == 0 for c in sp.stages + [sp.latent_dim]) and sp.expand == 2)
         found = None
         if ok:
-            ipw, nst = self.lds_ipw, len(sp.stages)
+            nst = len(sp.stages)
             cpu = lambda *shape: torch.empty(*shape, dtype=BF16)                                 # noqa: E731
-            for s0 in range(nst):
+
+            def fits(s0, s1, ipw_top, ipw_bot):
                 cin = c_stem if s0 == 0 else sp.stages[s0 - 1]
                 side = h >> s0
                 if side >> (nst - s0) < 1 or side > 64:
-                    continue
+                    return False
+                nn = max(ipw_top, ipw_bot)
                 try:
-                    widths = {}
-                    prog, _, _, _ = self._lds_build(P, wc, cpu(ipw, side, side, cin),
-                                                    lambda pre, i, widths=widths: torch.empty(ipw, P[f"{pre}t_embeddings.{i}.layers.2.bias"].shape[0]),
-                                                    ipw, s0, ipw, cpu)
-                    prog.check()
-                    found = s0
-                    break
+                    progs, _ = self._lds_build(P, wc, cpu(nn, side, side, cin),
+                                               lambda pre, i: torch.empty(nn, P[f"{pre}t_embeddings.{i}.layers.2.bias"].shape[0]),
+                                               nn, s0, s1, ipw_top, ipw_bot, cpu)
+                    for prog, _, _ in progs:
+                        prog.check()
+                    return True
                 except (LdsOutOfSpace, RuntimeError, AssertionError):
-                    continue
+                    return False
+
+            for s0 in range(nst):
+                if fits(s0, s0, self.lds_ipw, self.lds_ipw):
+                    found = (s0, s0, self.lds_ipw)
+                    deep = self.lds_ipw_deep
+                    while deep > self.lds_ipw and found[1] == s0:
+                        for s1 in range(s0 + 1, nst):
+                            if fits(s0, s1, self.lds_ipw, deep):
+                                found = (s0, s1, deep)
+                                break
+                        deep //= 2
+                    break
         self._lds_s0[key] = found
         return found
 
-    def _lds_run(self, P, wc, z: Tensor, temb: Callable[[str, int], Tensor], n: int, s0: int) -> Tensor:
+    def _lds_run(self, P, wc, z: Tensor, temb: Callable[[str, int], Tensor], n: int, plan) -> Tensor:
         dev = z.device
+        s0, s1, deep = plan
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=BF16)                        # noqa: E731
-        prog, out, nbytes, flops = self._lds_build(P, wc, z, temb, n, s0, self.lds_ipw, new)
-        arr, size = prog.table()
-        blob = self._stage_table(arr, size, dev, "lds")
-        ops._launch("unet_lds_kernel", lambda: (nbytes, flops, f"{len(arr) - 1} ops from stage {s0}"),
-                    lambda: hip.call("ddpm_unet_lds_run", blob.data_ptr(), arr, len(arr), n, prog.ipw, prog.act, hip.stream()))
+        progs, out = self._lds_build(P, wc, z, temb, n, s0, s1, self.lds_ipw, deep, new)
+        for k, (prog, nbytes, flops) in enumerate(progs):
+            arr, size = prog.table()
+            blob = self._stage_table(arr, size, dev, f"lds{k}")
+            ops._launch("unet_lds_kernel", lambda nbytes=nbytes, flops=flops, arr=arr, prog=prog: (nbytes, flops, f"{len(arr) - 1} ops, {prog.ipw} images per workgroup"),
+                        lambda blob=blob, arr=arr, prog=prog: hip.call("ddpm_unet_lds_run", blob.data_ptr(), arr, len(arr), n, prog.ipw, prog.act, hip.stream()))
         return out
 
     def _launch_wgrad_group(self, pending, dev) -> None:

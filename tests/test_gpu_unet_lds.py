@@ -169,8 +169,9 @@ def test_program_checks_reject_bad_tables(dev):
         p.check()
 
 
-@pytest.mark.parametrize("size,c,n,act,ipw", [(32, 1, 5, "gelu", 1), (64, 3, 3, "gelu", 1), (32, 3, 4, "silu", 1), (32, 1, 7, "gelu", 2), (16, 3, 3, "gelu", 1)])
-def test_whole_network_inference_through_lds_matches_layer_by_layer_path_and_oracle(dev, size, c, n, act, ipw):
+@pytest.mark.parametrize("size,c,n,act,ipw,deep", [(32, 1, 5, "gelu", 1, 8), (64, 3, 3, "gelu", 1, 8), (32, 3, 4, "silu", 1, 1), (32, 1, 7, "gelu", 2, 4),
+                                                   (16, 3, 3, "gelu", 1, 8), (32, 1, 19, "gelu", 1, 8)])
+def test_whole_network_inference_through_lds_matches_layer_by_layer_path_and_oracle(dev, size, c, n, act, ipw, deep):
     """BaseUNet.forward in inference: the engine's one-launch LDS path for the low-resolution stages against its layer-by-layer
     kernels (same weights, same input: equal to a few bf16 roundings) and against the oracle (5e-2, the whole-network drift
     bound of test_gpu_unet.py).  Reference: unets.py:100-132,206-240 there."""
@@ -181,15 +182,16 @@ def test_whole_network_inference_through_lds_matches_layer_by_layer_path_and_ora
     t = (hash_uniform((n,), 52) * 120).long().clamp_(0, 119) + 1
     eng = m.model._get_engine()
     m.model.use_graphs = False
-    eng.lds_ipw = ipw
+    eng.lds_ipw, eng.lds_ipw_deep = ipw, deep
     with torch.no_grad():
         eng.use_lds = False
         ref_gpu = m(x.to(dev), t.to(dev)).cpu()
         eng.use_lds = True
         eng._lds_s0.clear()
         got = m(x.to(dev), t.to(dev)).cpu()
-        s0 = eng._lds_first_stage(None, None, size, size, 32)
-        assert s0 is not None, "the LDS path did not engage"
+        plan = eng._lds_first_stage(None, None, size, size, 32)
+        assert plan is not None, "the LDS path did not engage"
+        print("LDS plan (first stage, first deep stage, images per workgroup there):", plan)
         ref = O.unet_forward(p, cfg, x, t)
     assert l2_err(got, ref_gpu) < 1.5e-2, l2_err(got, ref_gpu)
     assert l2_err(got, ref) < 5e-2, l2_err(got, ref)
