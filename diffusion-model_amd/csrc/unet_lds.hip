@@ -87,10 +87,12 @@ __device__ __forceinline__ void op_mask(const ddpm_lds_op& op, char* smem, int n
     for (int idx = tid; idx < R * vpr; idx += LT) {
         const int row = idx >> lv, v = idx & (vpr - 1);
         bf16x8 x = *(const bf16x8*)(smem + op.src_off + row * op.src_stride + v * 16);
-        unsigned m = 0;
-        if (n0 + (row >> lhw) < N) m = mk[((pix0 + row) * C + v * 8) >> 3];
+        if (mk) {                                      // (no keep bits: a plain copy between tiles)
+            unsigned m = 0;
+            if (n0 + (row >> lhw) < N) m = mk[((pix0 + row) * C + v * 8) >> 3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (m >> j) & 1 ? (bf16)((float)x[j] * op.mscale) : (bf16)0.f;
+            for (int j = 0; j < 8; ++j) x[j] = (m >> j) & 1 ? (bf16)((float)x[j] * op.mscale) : (bf16)0.f;
+        }
         *(bf16x8*)(smem + op.dst_off + row * op.dst_stride + v * 16) = x;
     }
 }
@@ -488,7 +490,7 @@ extern "C" long long ddpm_unet_lds_check(const ddpm_lds_op* ops, int nops, int i
                 DDPM_REQUIRE(extent(o.dst_off, o.dst_stride, ipw * hw_o, o.col0, o.cout), "unet_lds: op %d: bad tile", i);
                 break;
             case DDPM_LOP_MASK:
-                DDPM_REQUIRE(o.p[0] && o.col0 == 0, "unet_lds: op %d: no mask / column offset", i);
+                DDPM_REQUIRE(o.col0 == 0, "unet_lds: op %d: column offset", i);
                 DDPM_REQUIRE(extent(o.dst_off, o.dst_stride, ipw * hw_o, 0, o.cout) && extent(o.src_off, o.src_stride, ipw * hw_o, 0, o.cout),
                              "unet_lds: op %d: bad tile", i);
                 break;

@@ -1106,9 +1106,16 @@ class UNetEngine:
             return y, c
 
         def dec_first_half(zt, j):
-            """decoder stage j up to its transposed-convolution unit; zt: wide tile with Z in its first columns"""
+            """decoder stage j up to its transposed-convolution unit; zt: the stage input Z, in a tile wide enough for the
+            skip connection behind it or (after an inverted-residual block, whose expanded tile leaves no room for a wide
+            result) in a tile of its own that is copied into a wide one first"""
             prog = cur["p"]
             i, ci, co, b = nst - 1 - j, rs[j], outs[j], f"{d}layers.{j}.layers."
+            if zt.ch < 2 * ci:
+                wide = prog.tile(zt.w, 2 * ci)
+                prog.mask(zt, wide, None, ci)
+                prog.free(zt)
+                zt = wide
             prog.addt(zt, temb(d, j), ci)
             load(zt, skips[i], col0=ci)
             a = prog.tile(zt.w, ci)
@@ -1125,7 +1132,7 @@ class UNetEngine:
         def dec_second_half(up, j):
             co, b = outs[j], f"{d}layers.{j}.layers."
             a = sir(up, b + "3.", co)
-            return sir(a, b + "4.", co, wide=co)          # the next stage concatenates its skip behind these columns
+            return sir(a, b + "4.", co)
 
         def hand_over(t, ch):
             g = new(n, t.w, t.w, ch)
@@ -1211,12 +1218,14 @@ class UNetEngine:
             for s0 in range(nst):
                 if fits(s0, s0, self.lds_ipw, self.lds_ipw):
                     found = (s0, s0, self.lds_ipw)
+                    # the deep launch starts at the first stage of <= 4x4 pixels (where the weights outgrow the activations)
+                    # or the first one after s0, with as many images per workgroup as fit
+                    s1 = max(s0 + 1, next((i for i in range(nst) if (h >> (i + 1)) <= 4), nst))
                     deep = self.lds_ipw_deep
-                    while deep > self.lds_ipw and found[1] == s0:
-                        for s1 in range(s0 + 1, nst):
-                            if fits(s0, s1, self.lds_ipw, deep):
-                                found = (s0, s1, deep)
-                                break
+                    while s1 < nst and deep > self.lds_ipw:
+                        if fits(s0, s1, self.lds_ipw, deep):
+                            found = (s0, s1, deep)
+                            break
                         deep //= 2
                     break
         self._lds_s0[key] = found

@@ -419,7 +419,7 @@ int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t stream);
  *          training records: p[3] = raw input bf16 [N][pixels][cout], p[4] = result, p[5] = statistics fp32 [N][groups][2]
  *   DW     depthwise 3x3 + bias in place on dst: p[0] = fp32 [9][cout], p[1] = fp32 [cout]
  *   ADDT   columns [col0, col0+cout) of dst += p[0] (fp32 [N][cout]) broadcast over the pixels (unets.py:128,237)
- *   MASK   dst = src * keep bits of p[0] * mscale (the dropout on a block input, conv_block.py:57-58)
+ *   MASK   dst = src * keep bits of p[0] * mscale (the dropout on a block input, conv_block.py:57-58); p[0] = NULL: a copy
  * ddpm_unet_lds_check validates a HOST copy of the table and returns the LDS bytes the program needs (< 0: error);
  * ddpm_unet_lds_run validates the host copy, then launches ceil(N / ipw) workgroups that read the DEVICE copy. */
 enum { DDPM_LOP_END = 0, DDPM_LOP_LOAD = 1, DDPM_LOP_STORE = 2, DDPM_LOP_CONV = 3, DDPM_LOP_GN = 4, DDPM_LOP_DW = 5, DDPM_LOP_ADDT = 6,

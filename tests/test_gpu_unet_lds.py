@@ -151,9 +151,11 @@ def test_depthwise_and_block_input_mask(dev, c, w, ipw, n):
 
 def test_program_checks_reject_bad_tables(dev):
     p = LdsProgram(1, GELU)
-    with pytest.raises(Exception):
-        for _ in range(4):
-            p.tile(32, 32)                       # 4 x 80 KB does not fit 160 KB
+    from dm_amd.runtime.lds_program import LdsOutOfSpace
+    for _ in range(4):
+        p.tile(32, 32)                           # 4 x 80 KB live at once do not fit 160 KB
+    with pytest.raises(LdsOutOfSpace):
+        p.layout()
     p = LdsProgram(1, GELU)
     t = p.tile(16, 32)
     x = torch.zeros(2, 16, 16, 32, device=dev, dtype=torch.bfloat16)
