@@ -70,7 +70,7 @@ class LdsProgram:
         and the small ones fill in around them).  Returns the bytes of LDS the program needs."""
         if self._laid_out:
             return self.peak
-        end = len(self.ops)
+        end = len(self.ops) + 1                # (tiles never freed live to the end; a tile made after the last operation still counts)
         placed: List[Tile] = []
         self.peak = self.arena0
         for t in sorted(self.tiles, key=lambda t: (-t.nbytes, t.birth)):
