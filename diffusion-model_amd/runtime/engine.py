@@ -182,8 +182,10 @@ class UNetEngine:
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.conv_stats = os.environ.get("DDPM_CONV_STATS", "1") != "0"   # large images: GroupNorm sums from the convolution's tiles
         self.norm_on_load = os.environ.get("DDPM_NORM_ON_LOAD", "1") != "0"  # inference, large images: GroupNorm + act in the consumer's loader
-        # the low-resolution stages as one launch with the activations resident in LDS (csrc/unet_lds.hip) where the shapes fit
-        self.use_lds = os.environ.get("DDPM_LDS", "1") != "0"
+        # inference: the low-resolution stages as up to three launches with the activations resident in LDS (csrc/unet_lds.hip).
+        # Off unless asked for (DDPM_LDS=1): at the benchmarked batch sizes the per-layer kernels are faster (a workgroup that
+        # carries its images through every layer streams every weight itself, and the latency of that stream is not hidden)
+        self.use_lds = os.environ.get("DDPM_LDS", "0") == "1"
         self.lds_ipw = int(os.environ.get("DDPM_LDS_IPW", "1"))      # images per workgroup of that launch ...
         self.lds_ipw_deep = int(os.environ.get("DDPM_LDS_IPW_DEEP", "8"))   # ... and of the launch that holds the deepest stages
         self._lds_s0: Dict[Tuple, Optional[int]] = {}
