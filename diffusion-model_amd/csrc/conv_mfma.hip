@@ -18,6 +18,7 @@
 int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_small.hip
 int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream);    // conv_thin.hip
 int ddpm_conv_img_try(const ddpm_conv_desc* d, hipStream_t stream, int plain_too);   // conv_img.hip
+int ddpm_conv_pipe_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_pipe.hip
 
 struct ConvArgs {
     ConvGeom g;
@@ -449,6 +450,8 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
         DDPM_REQUIRE(ddpm_conv_gn_part_tiles(d) > 0, "conv: no per-tile GroupNorm sums for this problem (ask ddpm_conv_gn_part_tiles first)");
         return conv_general(d, stream);
     }
+    // deep, wide convolutions at batch sizes that fill the machine: the pipelined 256 x 128 tile kernel (matrix-core bound)
+    if (const int rc = ddpm_conv_pipe_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_PIPE; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     // 3x3 convolutions on 2x2 / 4x4 images (the deepest stages) have their own kernel
     if (const int rc = ddpm_conv_small_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_SMALL; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     // whole-image tiles: the unit's GroupNorm (forward) or its backward (data-gradient launches) runs in the same launch

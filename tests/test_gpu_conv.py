@@ -518,3 +518,53 @@ def test_conv_normalises_and_activates_on_load(dev, n, ci, co, h, wd, groups, ac
     a = (lambda v: v) if act == "none" else O.act_fn(act)
     y_ref = F.conv2d(r16(a(F.group_norm(x, groups, gamma, beta, eps=1e-5))), w, b)
     assert_rel(nchw(got), y_ref, 1e-2)
+
+
+PIPE_CASES = [
+    # kind, N, C0, C1, Cout, W, act, with residual
+    (hip.CONV_3X3_S1, 3, 128, 0, 128, 16, "none", False),
+    (hip.CONV_3X3_S1, 5, 256, 0, 256, 8, "gelu", True),        # 4 images per tile, ragged
+    (hip.CONV_3X3_S1, 19, 256, 0, 512, 4, "none", False),      # 16 images per tile, ragged; four column tiles
+    (hip.CONV_3X3_S1, 17, 512, 0, 256, 4, "silu", False),
+    (hip.CONV_3X3_S1, 2, 128, 128, 128, 16, "none", True),     # two concatenated sources
+    (hip.CONV_3X3_S1, 6, 64, 0, 128, 8, "none", False),        # a single 64-channel chunk: 9 steps
+    (hip.CONV_1X1, 3, 128, 0, 256, 8, "gelu", False),
+    (hip.CONV_1X1, 9, 512, 0, 256, 4, "none", True),
+    (hip.CONV_1X1, 2, 64, 0, 128, 16, "none", False),
+]
+
+
+@pytest.mark.parametrize("kind,n,c0,c1,co,w_,act,with_res", PIPE_CASES)
+def test_pipelined_wide_kernel_forward_and_dgrad(dev, kind, n, c0, c1, co, w_, act, with_res):
+    """The matrix-core-bound kernel (256 x 128 tiles, three-deep weight pipeline), forced onto small problems: forward with
+    bias / activation / residual / two sources, and the data-gradient (the same convolution on the flipped, transposed
+    weight copy), against torch fp32 on the same bf16 operands."""
+    from oracle import ref_cpu as O
+    ci = c0 + c1
+    k = 3 if kind == hip.CONV_3X3_S1 else 1
+    w = r16(hash_normal((co, ci, k, k), 1) * (1.0 / (ci * k * k)) ** 0.5)
+    b = hash_normal((co,), 2) * 0.1
+    x = r16(hash_normal((n, ci, w_, w_), 3))
+    res = r16(hash_normal((n, co, w_, w_), 5))
+    ref = torch_ref(kind, x, w, b)
+    if act != "none":
+        ref = O.act_fn(act)(ref)
+    if with_res:
+        ref = ref + res
+    prev = hip.lib().ddpm_conv_pipe_mode(1)
+    try:
+        xd = nhwc(x, dev)
+        x0, x1 = (xd[..., :c0].contiguous(), xd[..., c0:].contiguous()) if c1 else (xd, None)
+        y = ops.conv_forward(kind, x0, pack.pack_fwd(kind, w.to(dev)), b.to(dev), co, x1=x1, act=hip.ACT.get(act, 0) if act != "none" else 0,
+                             res=nhwc(res, dev) if with_res else None)
+        assert hip.lib().ddpm_conv_last_kernel() == 5, "the pipelined kernel did not take the launch"
+        assert_rel(nchw(y), ref)
+        if ci % 128 == 0 and co % 64 == 0:
+            gy = r16(hash_normal((n, co, w_, w_), 4))
+            xg = x.clone().requires_grad_(True)
+            (gref,) = torch.autograd.grad(torch_ref(kind, xg, w, None), xg, gy)
+            gx = ops.conv_forward(pack.DGRAD_KIND[kind], nhwc(gy, dev), pack.pack_dgrad(kind, w.to(dev)), None, ci)
+            assert hip.lib().ddpm_conv_last_kernel() == 5
+            assert_rel(nchw(gx), gref)
+    finally:
+        hip.lib().ddpm_conv_pipe_mode(prev)
