@@ -39,45 +39,64 @@ struct PipeArgs {
     int ntaps, w_rows, Cout, out_cs, act;
 };
 
+// NTAPS = 9 (3x3) or 1 (1x1).  The K loop is unrolled over groups of U steps so that every index that selects a register set
+// or a tap is a compile-time constant: U is a multiple of 3 (the weight ring and its three register sets) and, for 1x1, of 2
+// (the two patch buffers).  Loads past the last step are clamped to it instead of branched around (a redundant tile that
+// nobody reads): with loads inside branches the compiler can no longer count which of them a wait is for, and waits for all.
+template <int NTAPS>
 __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
+    constexpr int U = NTAPS == 9 ? 9 : 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int wm = wave & 3, wn = wave >> 2;
     const long long row0 = (long long)blockIdx.x * BM;
     const int co0 = blockIdx.y * BN;
-    const int Cin = a.C0 + a.C1, NC = Cin / CKP, S = NC * a.ntaps;
+    const int Cin = a.C0 + a.C1, NC = Cin / CKP, S = NC * NTAPS;
     char* s_w = smem + 2 * P_BYTES;
 
     // ---- staging roles: a thread moves 4 16-byte pieces of a patch chunk and 2 of a weight tile
     const int prow = tid >> 3, part = tid & 7;                                // pieces: row = prow + 64 u, 8 pieces per row
+    bool rok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rok[u] = row0 + prow + 64 * u < a.rows_total;
     auto load_patch = [&](bf16x8 (&v)[4], int c) {
         const int ch = c * CKP;
         const bool s1 = ch >= a.C0;
         const bf16* src = s1 ? a.in1 : a.in0;
         const int cs = s1 ? a.C1 : a.C0, cc = (s1 ? ch - a.C0 : ch) + part * 8;
+        const bf16* p = src + (row0 + prow) * cs + cc;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long long row = row0 + prow + 64 * u;
+            // rows past the end of the tensor read the tile's first row (always valid) and are zeroed: no branch around a load
+            v[u] = *(const bf16x8*)(rok[u] ? p + (long long)64 * u * cs : src + row0 * cs + cc);
+            if (!rok[u]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
-            if (row < a.rows_total) v[u] = *(const bf16x8*)(src + row * cs + cc);
+                for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+            }
         }
     };
-    auto store_patch = [&](const bf16x8 (&v)[4], int c) {
-        char* p = smem + (c & 1) * P_BYTES + part * 16;
+    auto store_patch = [&](const bf16x8 (&v)[4], int buf) {
+        char* p = smem + buf * P_BYTES + part * 16;
 #pragma unroll
         for (int u = 0; u < 4; ++u) *(bf16x8*)(p + (prow + 64 * u) * RS) = v[u];
     };
-    auto load_w = [&](bf16x8 (&v)[2], int s) {
-        const int c = s / a.ntaps, tap = s - c * a.ntaps;
-        const bf16* wp = a.w + ((long long)tap * a.w_rows + co0 + prow) * Cin + c * CKP + part * 8;
+    const bf16* wbase = a.w + ((long long)co0 + prow) * Cin + part * 8;
+    const long long wslice = (long long)a.w_rows * Cin;
+    auto load_w = [&](bf16x8 (&v)[2], int c, int tap) {
+        const bf16* wp = wbase + tap * wslice + c * CKP;
 #pragma unroll
         for (int u = 0; u < 2; ++u) v[u] = *(const bf16x8*)(wp + (long long)64 * u * Cin);
     };
-    auto store_w = [&](const bf16x8 (&v)[2], int s) {
-        char* p = s_w + (s % 3) * W_BYTES + part * 16;
+    auto store_w = [&](const bf16x8 (&v)[2], int slot) {
+        char* p = s_w + slot * W_BYTES + part * 16;
 #pragma unroll
         for (int u = 0; u < 2; ++u) *(bf16x8*)(p + (prow + 64 * u) * RS) = v[u];
+    };
+    // weight tile of flat step s (clamped to the last one)
+    auto load_w_step = [&](bf16x8 (&v)[2], int s) {
+        s = s < S ? s : S - 1;
+        if constexpr (NTAPS == 9) { const int c = s / 9; load_w(v, c, s - c * 9); }
+        else load_w(v, s, 0);
     };
 
     // ---- this lane's two A rows (positions) and their pixel coordinates
@@ -86,8 +105,8 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
         arow[mt] = wm * 64 + mt * 32 + r;
         const int p = arow[mt] & (a.hw - 1);
-        apy[mt] = a.W ? p >> a.lw : 0;
-        apx[mt] = a.W ? p & (a.W - 1) : 0;
+        apy[mt] = NTAPS == 9 ? p >> a.lw : 0;
+        apx[mt] = NTAPS == 9 ? p & (a.W - 1) : 0;
     }
     const int boff = (wn * 64 + r) * RS + h * 16;
 
@@ -99,16 +118,15 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    auto compute = [&](int s) {
-        const int c = s / a.ntaps, tap = s - c * a.ntaps;
-        const char* pb = smem + (c & 1) * P_BYTES;
-        const char* wb = s_w + (s % 3) * W_BYTES + boff;
-        const int dy = a.ntaps == 9 ? tap / 3 - 1 : 0, dx = a.ntaps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    auto compute = [&](int pbuf, int slot, int tap) {
+        const char* pb = smem + pbuf * P_BYTES;
+        const char* wb = s_w + slot * W_BYTES + boff;
+        const int dy = NTAPS == 9 ? tap / 3 - 1 : 0, dx = NTAPS == 9 ? tap % 3 - 1 : 0;
         const char* ap[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int ny = apy[mt] + dy, nx = apx[mt] + dx;
-            const bool ok = a.ntaps == 1 || (ny >= 0 && ny < a.W && nx >= 0 && nx < a.W);
+            const bool ok = NTAPS == 1 || (ny >= 0 && ny < a.W && nx >= 0 && nx < a.W);
             ap[mt] = ok ? pb + (arow[mt] + dy * a.W + dx) * RS + h * 16 : smem + ZOFF + h * 16;
         }
 #pragma unroll
@@ -124,49 +142,43 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
         }
     };
 
-    // ---- prologue: zero row, patch of chunk 0, weight tiles of steps 0 and 1 in LDS; step 2's in registers
+    // ---- prologue: zero row, patch of chunk 0, weight tiles of steps 0 and 1 in LDS; step 2's in registers (set 2)
     if (tid < 64) ((float*)(smem + ZOFF))[tid] = 0.f;
-    bf16x8 pr[4], wa[2], wb2[2];
+    bf16x8 pr[4], wr[3][2];
     load_patch(pr, 0);
-    load_w(wa, 0);
-    if (S > 1) load_w(wb2, 1);
+    load_w_step(wr[0], 0);
+    load_w_step(wr[1], 1);
     store_patch(pr, 0);
-    store_w(wa, 0);
-    if (S > 1) store_w(wb2, 1);
-    if (S > 2) load_w(wa, 2);
+    store_w(wr[0], 0);
+    store_w(wr[1], 1);
+    load_w_step(wr[2], 2);
     __syncthreads();
 
-    // the patch of the next chunk is fetched at the chunk's first step and written at its third (1x1: its only) one
-    const int pw = a.ntaps > 2 ? 2 : a.ntaps - 1;
-    // steps in pairs so that the two register sets of the weight pipeline have fixed names:
-    //   even step s: wa holds tile s + 2 (fetched during step s - 1); fetch tile s + 3 into wb2; multiply; write wa
-    //   odd  step s: wb2 holds tile s + 2;                            fetch tile s + 3 into wa;  multiply; write wb2
-    for (int s = 0; s < S; s += 2) {
-        if (s + 3 < S) load_w(wb2, s + 3);
-        {
-            const int c = s / a.ntaps, tap = s - c * a.ntaps;
-            if (c + 1 < NC && tap == 0) load_patch(pr, c + 1);
+    // Step s = g U + t: the weight tile of step s + 3 is fetched into register set t % 3, the tile of step s + 2 (fetched one
+    // step ago, set (t + 2) % 3) is written to ring slot (t + 2) % 3 after the multiplications, one barrier ends the step.
+    // 3x3: a group is one 64-channel chunk, t its tap; the next chunk's patch is fetched at tap 0 and written at tap 2.
+    // 1x1: every step is a chunk of its own; the next one's patch is fetched and written within the step.
+    const int G = (S + U - 1) / U;
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const int s = g * U + t;
+            load_w_step(wr[t % 3], s + 3);
+            if constexpr (NTAPS == 9) {
+                if (t == 0) load_patch(pr, g + 1 < NC ? g + 1 : NC - 1);
+                compute(g & 1, t % 3, t);
+            } else {
+                load_patch(pr, s + 1 < NC ? s + 1 : NC - 1);
+                if (s < S) compute(t & 1, t % 3, 0);
+            }
+            store_w(wr[(t + 2) % 3], (t + 2) % 3);
+            if constexpr (NTAPS == 9) {
+                if (t == 2) store_patch(pr, (g + 1) & 1);
+            } else {
+                store_patch(pr, (t + 1) & 1);
+            }
+            __syncthreads();
         }
-        compute(s);
-        if (s + 2 < S) store_w(wa, s + 2);
-        {
-            const int c = s / a.ntaps, tap = s - c * a.ntaps;
-            if (c + 1 < NC && tap == pw) store_patch(pr, c + 1);
-        }
-        __syncthreads();
-        if (s + 1 >= S) break;
-        if (s + 4 < S) load_w(wa, s + 4);
-        {
-            const int c = (s + 1) / a.ntaps, tap = (s + 1) - c * a.ntaps;
-            if (c + 1 < NC && tap == 0) load_patch(pr, c + 1);
-        }
-        compute(s + 1);
-        if (s + 3 < S) store_w(wb2, s + 3);
-        {
-            const int c = (s + 1) / a.ntaps, tap = (s + 1) - c * a.ntaps;
-            if (c + 1 < NC && tap == pw) store_patch(pr, c + 1);
-        }
-        __syncthreads();
     }
 
     // ---- epilogue: bias + activation -> bf16 tile in LDS -> 16-byte NHWC stores (+ residual)
@@ -247,13 +259,15 @@ int ddpm_conv_pipe_try(const ddpm_conv_desc* d, hipStream_t stream) {
     a.ntaps = W ? 9 : 1; a.w_rows = d->w_rows; a.Cout = d->Cout; a.out_cs = d->out_cs; a.act = d->act;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_pipe_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
             ddpm_set_error("conv_pipe: cannot reserve %d bytes of LDS", LDS_BYTES);
             return -1;
         }
         attr = true;
     }
     dim3 grid((unsigned)((rows + BM - 1) / BM), (unsigned)(d->CoutW / BN));
-    hipLaunchKernelGGL(conv_pipe_kernel, grid, dim3(PT), LDS_BYTES, stream, a);
+    if (W) hipLaunchKernelGGL(conv_pipe_kernel<9>, grid, dim3(PT), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(conv_pipe_kernel<1>, grid, dim3(PT), LDS_BYTES, stream, a);
     return ddpm_check_launch("conv_pipe") == DDPM_OK ? 1 : -1;
 }
