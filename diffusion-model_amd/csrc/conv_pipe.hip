@@ -118,28 +118,47 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    auto compute = [&](int pbuf, int slot, int tap) {
+    // Fragment addresses of a step: the two A rows of this lane under the step's tap, and its first B row.
+    auto step_ptrs = [&](int pbuf, int slot, int tap, const char* (&ap)[2], const char*& wb) {
         const char* pb = smem + pbuf * P_BYTES;
-        const char* wb = s_w + slot * W_BYTES + boff;
+        wb = s_w + slot * W_BYTES + boff;
         const int dy = NTAPS == 9 ? tap / 3 - 1 : 0, dx = NTAPS == 9 ? tap % 3 - 1 : 0;
-        const char* ap[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int ny = apy[mt] + dy, nx = apx[mt] + dx;
             const bool ok = NTAPS == 1 || (ny >= 0 && ny < a.W && nx >= 0 && nx < a.W);
             ap[mt] = ok ? pb + (arow[mt] + dy * a.W + dx) * RS + h * 16 : smem + ZOFF + h * 16;
         }
+    };
+    // The fragments of a step's first k-step can be read BEFORE the barrier that ends the previous step (what they read was
+    // published one barrier earlier): the matrix pipe then has work the moment the barrier opens instead of waiting for eight
+    // waves' LDS reads to drain.  f = {a0, a1, b0, b1} of k-step 0, or fetched here when PRE is false.
+    auto compute = [&](int pbuf, int slot, int tap, bf16x8 (&f)[4], bool pre) {
+        const char* ap[2];
+        const char* wb;
+        step_ptrs(pbuf, slot, tap, ap, wb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bf16x8 a0 = *(const bf16x8*)(ap[0] + k * 32);      // (the zero row is as long as a patch row)
-            const bf16x8 a1 = *(const bf16x8*)(ap[1] + k * 32);
-            const bf16x8 b0 = *(const bf16x8*)(wb + k * 32);
-            const bf16x8 b1 = *(const bf16x8*)(wb + 32 * RS + k * 32);
+            bf16x8 a0, a1, b0, b1;
+            if (k == 0 && pre) { a0 = f[0]; a1 = f[1]; b0 = f[2]; b1 = f[3]; }
+            else {
+                a0 = *(const bf16x8*)(ap[0] + k * 32);               // (the zero row is as long as a patch row)
+                a1 = *(const bf16x8*)(ap[1] + k * 32);
+                b0 = *(const bf16x8*)(wb + k * 32);
+                b1 = *(const bf16x8*)(wb + 32 * RS + k * 32);
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
+    };
+    auto prefetch = [&](int pbuf, int slot, int tap, bf16x8 (&f)[4]) {
+        const char* ap[2];
+        const char* wb;
+        step_ptrs(pbuf, slot, tap, ap, wb);
+        f[0] = *(const bf16x8*)ap[0]; f[1] = *(const bf16x8*)ap[1];
+        f[2] = *(const bf16x8*)wb; f[3] = *(const bf16x8*)(wb + 32 * RS);
     };
 
     // ---- prologue: zero row, patch of chunk 0, weight tiles of steps 0 and 1 in LDS; step 2's in registers (set 2)
@@ -153,6 +172,8 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
     store_w(wr[1], 1);
     load_w_step(wr[2], 2);
     __syncthreads();
+    bf16x8 fr[4];
+    if constexpr (NTAPS == 9) prefetch(0, 0, 0, fr);
 
     // Step s = g U + t: the weight tile of step s + 3 is fetched into register set t % 3, the tile of step s + 2 (fetched one
     // step ago, set (t + 2) % 3) is written to ring slot (t + 2) % 3 after the multiplications, one barrier ends the step.
@@ -166,14 +187,18 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
             load_w_step(wr[t % 3], s + 3);
             if constexpr (NTAPS == 9) {
                 if (t == 0) load_patch(pr, g + 1 < NC ? g + 1 : NC - 1);
-                compute(g & 1, t % 3, t);
+                compute(g & 1, t % 3, t, fr, true);
             } else {
                 load_patch(pr, s + 1 < NC ? s + 1 : NC - 1);
-                if (s < S) compute(t & 1, t % 3, 0);
+                if (s < S) compute(t & 1, t % 3, 0, fr, false);
             }
             store_w(wr[(t + 2) % 3], (t + 2) % 3);
             if constexpr (NTAPS == 9) {
                 if (t == 2) store_patch(pr, (g + 1) & 1);
+                // first fragments of the next step (its weight slot was written two steps ago, its patch at tap 2 of the
+                // previous chunk at the latest: both published by barriers already passed)
+                if (t + 1 < U) prefetch(g & 1, (t + 1) % 3, t + 1, fr);
+                else prefetch((g + 1) & 1, 0, 0, fr);
             } else {
                 store_patch(pr, (t + 1) & 1);
             }
