@@ -11,6 +11,7 @@
 //     64 x 64 = 2 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16: each LDS fragment read feeds two MFMAs;
 //   * the 256 positions are whole images (1, 4 or 16 of them), so the input patch of a 64-channel chunk is staged in LDS
 //     ONCE for all nine taps: a tap reads the neighbour pixel's row, or a row of zeros outside the image;
+//   * the loader fuses the channel concat of two sources and the broadcast add of the time embedding;
 //   * K runs as a flat sequence of steps (64-channel chunk, tap); the weight tile of a step ([128][64], 16 KB) sits in a ring
 //     of three LDS buffers, fetched from L2 into registers three steps ahead and written to LDS two steps ahead; the next
 //     chunk's patch is fetched and written the same way into the second patch buffer.  One barrier per step, 16 MFMAs per
@@ -32,6 +33,7 @@ static_assert(BM * OS <= 2 * P_BYTES + 3 * W_BYTES, "the output tile reuses the 
 
 struct PipeArgs {
     const bf16* in0; const bf16* in1; int C0, C1;
+    const float* in_add;                        // optional fp32 [N][C0]: broadcast add on source 0 (the stage-input time embedding)
     const bf16* w; const float* bias;
     bf16* out; const bf16* res;
     long long rows_total;                       // N * H * W
@@ -43,7 +45,7 @@ struct PipeArgs {
 // or a tap is a compile-time constant: U is a multiple of 3 (the weight ring and its three register sets) and, for 1x1, of 2
 // (the two patch buffers).  Loads past the last step are clamped to it instead of branched around (a redundant tile that
 // nobody reads): with loads inside branches the compiler can no longer count which of them a wait is for, and waits for all.
-template <int NTAPS>
+template <int NTAPS, bool HAS_ADD>
 __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
     constexpr int U = NTAPS == 9 ? 9 : 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,16 +61,35 @@ __global__ __launch_bounds__(PT) void conv_pipe_kernel(const PipeArgs a) {
     bool rok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) rok[u] = row0 + prow + 64 * u < a.rows_total;
+    // image of each of this thread's four patch rows (for the broadcast add); rows of one thread are 64 apart
+    long long pimg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pimg[u] = (row0 + prow + 64 * u) >> a.lhw;
     auto load_patch = [&](bf16x8 (&v)[4], int c) {
         const int ch = c * CKP;
         const bool s1 = ch >= a.C0;
         const bf16* src = s1 ? a.in1 : a.in0;
         const int cs = s1 ? a.C1 : a.C0, cc = (s1 ? ch - a.C0 : ch) + part * 8;
         const bf16* p = src + (row0 + prow) * cs + cc;
+        const bool add = HAS_ADD && !s1;
+        f32x4 ad[4][2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // rows past the end of the tensor read the tile's first row (always valid) and are zeroed: no branch around a load
             v[u] = *(const bf16x8*)(rok[u] ? p + (long long)64 * u * cs : src + row0 * cs + cc);
+            if constexpr (HAS_ADD) {
+                const float* ap = a.in_add + (rok[u] ? pimg[u] : (row0 >> a.lhw)) * a.C0 + (s1 ? 0 : cc);
+                ad[u][0] = *(const f32x4*)ap; ad[u][1] = *(const f32x4*)(ap + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (HAS_ADD) {
+                if (add) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[u][j] = (bf16)((float)v[u][j] + ad[u][0][j]); v[u][4 + j] = (bf16)((float)v[u][4 + j] + ad[u][1][j]); }
+                }
+            }
             if (!rok[u]) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
@@ -261,7 +282,7 @@ extern "C" int ddpm_conv_pipe_mode(int mode) {
 int ddpm_conv_pipe_try(const ddpm_conv_desc* d, hipStream_t stream) {
     if (g_pipe_mode < 0) return 0;
     if (d->kind != CONV_3X3_S1 && d->kind != CONV_1X1) return 0;
-    if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->in_add || d->sum_out || d->out2 || d->gn_gamma || d->gnb_raw || d->gn_part ||
+    if (d->out_mode != OUT_BF16_NHWC || d->in_mask || d->out_mask || d->sum_out || d->out2 || d->gn_gamma || d->gnb_raw || d->gn_part ||
         d->in_affine || d->C0_used || !d->out)
         return 0;
     if (d->C0 % CKP || d->C1 % CKP || d->CoutW % BN || d->Cout != d->CoutW || d->out_cs % 8) return 0;
@@ -276,23 +297,33 @@ int ddpm_conv_pipe_try(const ddpm_conv_desc* d, hipStream_t stream) {
     if (g_pipe_mode == 0 && (rows * (d->CoutW / BN) < 256ll * BM || (d->C0 + d->C1) * (W ? 9 : 1) < 512)) return 0;
     PipeArgs a;
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.C0 = d->C0; a.C1 = d->C1;
+    a.in_add = d->in_add;
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out; a.res = (const bf16*)d->res;
     a.rows_total = rows;
     a.W = W; a.hw = W ? W * W : 1; a.lw = 0; a.lhw = 0;
     while ((1 << a.lw) < W) ++a.lw;
     a.lhw = 2 * a.lw;
+    if (!W) {                                   // 1x1: the image index of a row (only the broadcast add needs it)
+        const int hw = d->IH * d->IW;
+        if (d->in_add && (hw & (hw - 1))) return 0;
+        while ((1 << a.lhw) < hw) ++a.lhw;
+    }
     a.ntaps = W ? 9 : 1; a.w_rows = d->w_rows; a.Cout = d->Cout; a.out_cs = d->out_cs; a.act = d->act;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_pipe_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_pipe_kernel<9, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pipe_kernel<9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pipe_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pipe_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
             ddpm_set_error("conv_pipe: cannot reserve %d bytes of LDS", LDS_BYTES);
             return -1;
         }
         attr = true;
     }
     dim3 grid((unsigned)((rows + BM - 1) / BM), (unsigned)(d->CoutW / BN));
-    if (W) hipLaunchKernelGGL(conv_pipe_kernel<9>, grid, dim3(PT), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(conv_pipe_kernel<1>, grid, dim3(PT), LDS_BYTES, stream, a);
+    if (W && a.in_add) hipLaunchKernelGGL((conv_pipe_kernel<9, true>), grid, dim3(PT), LDS_BYTES, stream, a);
+    else if (W) hipLaunchKernelGGL((conv_pipe_kernel<9, false>), grid, dim3(PT), LDS_BYTES, stream, a);
+    else if (a.in_add) hipLaunchKernelGGL((conv_pipe_kernel<1, true>), grid, dim3(PT), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((conv_pipe_kernel<1, false>), grid, dim3(PT), LDS_BYTES, stream, a);
     return ddpm_check_launch("conv_pipe") == DDPM_OK ? 1 : -1;
 }

@@ -406,7 +406,12 @@ class UNetEngine:
             gamma = P[norm + ".weight"] if norm else None
             beta = P[norm + ".bias"] if norm else None
             assert in_affine is None or (tape is None and norm and x1 is None and in_add is None)
-            if in_affine is None and bsc is None and norm and in_mask is None and out_mask is None and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups):
+            # deep, wide 3x3 convolutions at batch sizes that give every CU a 256-position tile: the matrix-core-bound kernel
+            # plus a GroupNorm launch beats the whole-image kernels that finish the GroupNorm themselves (those are sized
+            # for the latency-bound small batches)
+            wide = ops.conv_pipe_wins(kind, x0.v, None if x1 is None else x1.v, cout) and in_mask is None and out_mask is None
+            if (not wide and in_affine is None and bsc is None and norm and in_mask is None and out_mask is None
+                    and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups)):
                 # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
                 raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                                  in_add=None if in_add is None else in_add.v,

@@ -128,6 +128,17 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     return out if gn is None else (out, y, stats)
 
 
+def conv_pipe_wins(kind: int, x0: Tensor, x1: Optional[Tensor], cout: int) -> bool:
+    """Whether a plain conv_forward of this problem runs on the pipelined 256 x 128 tile kernel (csrc/conv_pipe.hip) by the
+    library's own size rule: 3x3 stride 1 on 4x4 / 8x8 / 16x16 images, channel counts in its granules, and at least one
+    tile per CU."""
+    n, ih, iw, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    if kind != hip.CONV_3X3_S1 or ih != iw or iw not in (4, 8, 16) or c0 % 64 or c1 % 64 or cout % 128:
+        return False
+    return n * ih * iw * (cout // 128) >= 256 * 256 and (c0 + c1) * 9 >= 512
+
+
 def conv_gnb_fusable(kind: int, dy: Tensor, cout: int, groups: int, masked: bool = False) -> bool:
     """Whether conv_forward(kind, dy, ..., gnb=...) is available: kind = the data-gradient kind, dy = gradient of the unit's
     output ([N,H,W,C]), cout = channels of the data-gradient, groups = the unit's GroupNorm groups."""

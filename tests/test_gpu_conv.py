@@ -531,6 +531,8 @@ PIPE_CASES = [
     (hip.CONV_1X1, 3, 128, 0, 256, 8, "gelu", False),
     (hip.CONV_1X1, 9, 512, 0, 256, 4, "none", True),
     (hip.CONV_1X1, 2, 64, 0, 128, 16, "none", False),
+    (hip.CONV_3X3_S1, 7, 128, 128, 128, 8, "add", False),      # decoder form: (Z + time embedding) ++ skip
+    (hip.CONV_1X1, 3, 128, 0, 128, 8, "add", False),
 ]
 
 
@@ -546,6 +548,11 @@ def test_pipelined_wide_kernel_forward_and_dgrad(dev, kind, n, c0, c1, co, w_, a
     b = hash_normal((co,), 2) * 0.1
     x = r16(hash_normal((n, ci, w_, w_), 3))
     res = r16(hash_normal((n, co, w_, w_), 5))
+    temb = None
+    if act == "add":                           # broadcast add on the first source, rounded to bf16 as the loader rounds it
+        temb = hash_normal((n, c0), 6)
+        x = torch.cat([r16(x[:, :c0] + temb.view(n, c0, 1, 1)), x[:, c0:]], 1)
+        act = "none"
     ref = torch_ref(kind, x, w, b)
     if act != "none":
         ref = O.act_fn(act)(ref)
@@ -555,8 +562,12 @@ def test_pipelined_wide_kernel_forward_and_dgrad(dev, kind, n, c0, c1, co, w_, a
     try:
         xd = nhwc(x, dev)
         x0, x1 = (xd[..., :c0].contiguous(), xd[..., c0:].contiguous()) if c1 else (xd, None)
+        if temb is not None:                   # hand the kernel the tensor WITHOUT the add
+            x0 = (x0.float() - temb.to(dev).view(n, 1, 1, c0)).bfloat16()
+            x_chk = (x0.float() + temb.to(dev).view(n, 1, 1, c0)).bfloat16()
+            ref = torch_ref(kind, torch.cat([nchw(x_chk), nchw(x1)], 1) if c1 else nchw(x_chk), w, b)
         y = ops.conv_forward(kind, x0, pack.pack_fwd(kind, w.to(dev)), b.to(dev), co, x1=x1, act=hip.ACT.get(act, 0) if act != "none" else 0,
-                             res=nhwc(res, dev) if with_res else None)
+                             res=nhwc(res, dev) if with_res else None, in_add=None if temb is None else temb.to(dev))
         assert hip.lib().ddpm_conv_last_kernel() == 5, "the pipelined kernel did not take the launch"
         assert_rel(nchw(y), ref)
         if ci % 128 == 0 and co % 64 == 0:
