@@ -198,6 +198,8 @@ def lib():
         for name, (args, res) in _PROTOS.items():
             fn = getattr(_lib, name)
             fn.argtypes, fn.restype = args, res
+        if os.environ.get("DDPM_CONV_PIPE", "1") == "0":     # A/B switch: never take the pipelined wide-convolution kernel
+            _lib.ddpm_conv_pipe_mode(-1)                      # (per thread: this one launches the forward passes)
     return _lib
 
 

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -134,7 +135,7 @@ def conv_pipe_wins(kind: int, x0: Tensor, x1: Optional[Tensor], cout: int) -> bo
     tile per CU."""
     n, ih, iw, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
-    if kind != hip.CONV_3X3_S1 or ih != iw or iw not in (4, 8, 16) or c0 % 64 or c1 % 64 or cout % 128:
+    if kind != hip.CONV_3X3_S1 or ih != iw or iw not in (4, 8, 16) or c0 % 64 or c1 % 64 or cout % 128 or os.environ.get("DDPM_CONV_PIPE", "1") == "0":
         return False
     return n * ih * iw * (cout // 128) >= 256 * 256 and (c0 + c1) * 9 >= 512
 
