@@ -2,6 +2,7 @@
 // ELBO-weighted loss forward/backward, time embedding, and the NCHW<->NHWC layout/precision bridges
 // at the UNet boundary.  All of them are HBM-streaming kernels: 16-byte vector accesses, grid capped
 // at a few blocks per CU with a grid-stride loop.
+#include <stdlib.h>
 #include "common.h"
 #include "ddpm_hip.h"
 
@@ -34,6 +35,23 @@ int ddpm_check_launch(const char* what) {
 
 extern "C" const char* ddpm_last_error(void) { return g_err; }
 extern "C" int ddpm_abi_version(void) { return 3; }
+
+// Reproducible sums (no counterpart in the reference, which leaves torch's own choice of reduction order alone): when on,
+// every launcher whose kernel combines per-workgroup partial sums with atomics runs that kernel as ONE workgroup, so the sum is
+// formed in a fixed order (slower; meant for parity runs).  Process-wide; initialised from DDPM_DETERMINISTIC=1.
+static int g_deterministic = -1;
+extern "C" int ddpm_set_deterministic(int on) {
+    const int prev = g_deterministic > 0;
+    g_deterministic = on ? 1 : 0;
+    return prev;
+}
+extern "C" int ddpm_deterministic(void) {
+    if (g_deterministic < 0) {
+        const char* e = getenv("DDPM_DETERMINISTIC");
+        g_deterministic = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_deterministic;
+}
 
 static inline int stream_grid(long long work_items, int block) {
     long long g = (work_items + block - 1) / block;
@@ -213,8 +231,8 @@ extern "C" int ddpm_elbo_fwd(const float* pred, const float* target, const int64
     DDPM_REQUIRE(pred && target && t && sched && loss, "elbo_fwd: null pointer");
     DDPM_REQUIRE(N > 0 && chw > 0 && chw % 4 == 0, "elbo_fwd: C*H*W must be a positive multiple of 4 (got %lld)", chw);
     if (hipMemsetAsync(loss, 0, sizeof(float), stream) != hipSuccess) return ddpm_check_launch("elbo_fwd memset");
-    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(stream_grid((long long)N * chw / 4, 256)), dim3(256), 0, stream, pred, target, t, sched, loss,
-                       N, chw, bce, weighted);
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(ddpm_deterministic() ? 1 : stream_grid((long long)N * chw / 4, 256)), dim3(256), 0, stream, pred,
+                       target, t, sched, loss, N, chw, bce, weighted);
     return ddpm_check_launch("elbo_fwd");
 }
 
@@ -291,7 +309,7 @@ extern "C" int ddpm_elbo_tanh_head(const float* pred, const float* target, const
     DDPM_REQUIRE(pred && target && t_ && sched && loss && dz && bias_grad, "elbo_tanh_head: null pointer");
     DDPM_REQUIRE(N > 0 && C > 0 && C <= 16 && HW > 0, "elbo_tanh_head: 1..16 image channels (got %d)", C);
     if (hipMemsetAsync(loss, 0, sizeof(float), stream) != hipSuccess) return ddpm_check_launch("elbo_tanh_head memset");
-    hipLaunchKernelGGL(elbo_tanh_head_kernel, dim3(stream_grid((long long)N * HW, 256)), dim3(256), 0, stream, pred, target,
+    hipLaunchKernelGGL(elbo_tanh_head_kernel, dim3(ddpm_deterministic() ? 1 : stream_grid((long long)N * HW, 256)), dim3(256), 0, stream, pred, target,
                        (const long long*)t_, sched, loss, (bf16*)dz, bias_grad, N, C, HW, weighted);
     return ddpm_check_launch("elbo_tanh_head");
 }
@@ -674,7 +692,8 @@ extern "C" int ddpm_colsum(const void* x, float* out, int64_t rows, int C, int c
     DDPM_REQUIRE(cvs <= 64, "colsum: C = %d must be at most 512", C);
     long long blocks = (rows * cvs + 256 * 16 - 1) / (256 * 16);
     if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    if (blocks < 1 || ddpm_deterministic()) blocks = 1;
+    DDPM_REQUIRE(rows / blocks < (1ll << 31), "colsum: too many rows for one workgroup");
     const int rpb = (int)((rows + blocks - 1) / blocks);
     blocks = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, out, (long long)rows, C, cs, rpb, cvs);

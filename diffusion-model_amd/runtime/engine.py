@@ -190,6 +190,10 @@ class UNetEngine:
         self.lds_ipw_deep = int(os.environ.get("DDPM_LDS_IPW_DEEP", "8"))   # ... and of the launch that holds the deepest stages
         self._lds_s0: Dict[Tuple, Optional[int]] = {}
         self._lds_pin: Dict[str, list] = {}
+        # reproducible gradients (parity runs): sums that the convolutions' epilogues would add with atomics (the per-image
+        # sums feeding the time-embedding MLPs) are taken by a fixed-order kernel from the stored gradient instead, and the
+        # library forms its scalar / column sums in one workgroup (ddpm_set_deterministic).  DDPM_DETERMINISTIC=1.
+        self.deterministic = os.environ.get("DDPM_DETERMINISTIC", "0") == "1"
         self.always_repack = False      # set while capturing a HIP graph: parameter updates then happen without Python
         self.phases = 1                 # backward in 1, 2 (decoder | encoder), 4 (each halved at its middle stage), 5 (the last
                                         # of those cut again after the first encoder convolution) or, for any larger value,
@@ -461,8 +465,15 @@ class UNetEngine:
                     # reads later
                     draw = torch.empty_like(raw)
                     dsum = self._take_zeros(n * c0, dev).view(n, c0) if in_add is not None else None
-                    x0.g = ops.conv_forward(dk, dy, wd, None, c0, res=x0.g, rows=c0, sum_out=dsum,
-                                            gnb=(raw, gamma, beta, groups, act, stats, gn_partials(cout, norm, name), draw))
+                    if dsum is not None and self.deterministic:
+                        # fixed-order sum of this convolution's own data-gradient, the other consumers' gradient added after it
+                        own = ops.conv_forward(dk, dy, wd, None, c0, rows=c0,
+                                               gnb=(raw, gamma, beta, groups, act, stats, gn_partials(cout, norm, name), draw))
+                        ops.spatial_sum(own, dsum)
+                        x0.g = own if x0.g is None else ops.gn_act_forward(own, None, None, 0, 0, res=x0.g)[0]
+                    else:
+                        x0.g = ops.conv_forward(dk, dy, wd, None, c0, res=x0.g, rows=c0, sum_out=dsum,
+                                                gnb=(raw, gamma, beta, groups, act, stats, gn_partials(cout, norm, name), draw))
                     out.g = None
                     wgrad(kind, x0.v, draw, cout, name, x1=None if x1 is None else x1.v,
                           in_add=None if in_add is None else in_add.v, in_mask=in_mask)
@@ -491,7 +502,12 @@ class UNetEngine:
                 # gradient of the broadcast add = per-image spatial sum of this conv's own data-gradient,
                 # accumulated in fp32 inside the kernel (x0.g, added afterwards, belongs to other consumers)
                 dsum = self._take_zeros(n * c0, dev).view(n, c0) if in_add is not None else None
-                x0.g = ops.conv_forward(dk, draw, wd, None, c0, res=x0.g, out_mask=in_mask, out_scale=mscale, rows=c0, sum_out=dsum)
+                if dsum is not None and self.deterministic and in_mask is None:
+                    own = ops.conv_forward(dk, draw, wd, None, c0, rows=c0)
+                    ops.spatial_sum(own, dsum)
+                    x0.g = own if x0.g is None else ops.gn_act_forward(own, None, None, 0, 0, res=x0.g)[0]
+                else:
+                    x0.g = ops.conv_forward(dk, draw, wd, None, c0, res=x0.g, out_mask=in_mask, out_scale=mscale, rows=c0, sum_out=dsum)
                 if in_add is not None:
                     in_add.g = dsum
                 if x1 is not None:

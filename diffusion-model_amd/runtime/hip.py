@@ -116,6 +116,8 @@ class LdsOp(C.Structure):
 LOP_END, LOP_LOAD, LOP_STORE, LOP_CONV, LOP_GN, LOP_DW, LOP_ADDT, LOP_MASK = range(8)
 
 _PROTOS = {
+    "ddpm_set_deterministic": ([_i], _i),
+    "ddpm_deterministic": ([], _i),
     "ddpm_unet_lds_arena0": ([], _i),
     "ddpm_unet_lds_reduce_bytes": ([], _i),
     "ddpm_unet_lds_max_bytes": ([], _i),

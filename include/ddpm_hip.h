@@ -41,6 +41,12 @@ enum { DDPM_OUT_BF16_NHWC = 0, DDPM_OUT_F32_NCHW = 1 };
 
 const char* ddpm_last_error(void);
 int ddpm_abi_version(void);
+/* Reproducible sums (no counterpart in the reference).  on != 0: the launchers whose kernels combine per-workgroup partial sums
+ * with atomics (ddpm_elbo_fwd, ddpm_elbo_tanh_head, ddpm_colsum) run them as one workgroup, so two passes over the same numbers
+ * give the same bits; the convolution entry points' sum_out stays an atomic sum (callers that need reproducible bits take the
+ * sum with ddpm_spatial_sum instead).  Process-wide, default off (or DDPM_DETERMINISTIC=1); returns the previous setting. */
+int ddpm_set_deterministic(int on);
+int ddpm_deterministic(void);
 
 /* ---- diffusion process (elementwise.hip) ------------------------------------------------------ */
 

@@ -831,3 +831,49 @@ def test_captured_backward_under_autograd_grad_and_inputs_subset(dev):
         if id(q) not in sub_ids:
             assert torch.equal(a, b)
     assert len(others) > 0
+
+
+def test_deterministic_mode_gives_bit_equal_gradients(dev):
+    """With reproducible sums switched on (DDPM_DETERMINISTIC=1; here through its two switches) two passes over the same
+    numbers give the same loss and the same gradient bits, through the eager module path and through the pipelined
+    two-stream graph driver, and the gradients still hold the whole-network bounds against the oracle."""
+    from dm_amd.optimizer import FusedAdam
+    from dm_amd.runtime import graphs, hip
+    prev = hip.lib().ddpm_set_deterministic(1)
+    try:
+        m, cfg, p = build(dev, 1, "gelu")
+        m.train()
+        m.model.use_graphs = False
+        m.model._get_engine().deterministic = True
+        n = 6
+        x0 = hash_uniform((n, 1, 32, 32), 71) * 2 - 1
+        t = torch.tensor([1, 17, 60, 61, 99, 120])
+        noise = hash_normal((n, 1, 32, 32), 72)
+        crit = ELBOLoss("mse")
+
+        def one_pass():
+            m.zero_grad(set_to_none=True)
+            x_t = m.q(x0.to(dev), t.to(dev), noise=noise.to(dev))
+            loss = crit(m, t.to(dev), m(x_t, t.to(dev)), x0.to(dev))["Loss"]
+            loss.backward()
+            return loss.detach().clone(), [q.grad.detach().clone() for q in m.parameters()]
+
+        la, ga = one_pass()
+        lb, gb = one_pass()
+        assert torch.equal(la, lb)
+        for (k, _), a, b in zip(m.named_parameters(), ga, gb):
+            assert torch.equal(a, b), k
+        _, gref = O.train_step_grads(p, cfg, O.make_schedule(120, 0.25), x0, t, noise)
+        check_grads(zip((k for k, _ in m.named_parameters()), ga), gref)
+        # the graph driver: two replays of the same batch with lr = 0
+        opt = FusedAdam(m.parameters(), lr=0.0)
+        step = graphs.PipelinedTrainStep(m, crit, opt, x0.to(dev), None, phases=4, t=t.to(dev), noise=noise.to(dev))
+        l1 = step.replay().clone()
+        g1 = [q.grad.detach().clone() for q in m.parameters()]
+        l2 = step.replay().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(l1, l2)
+        for (k, q), a in zip(m.named_parameters(), g1):
+            assert torch.equal(q.grad, a), k
+    finally:
+        hip.lib().ddpm_set_deterministic(prev)
