@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--phases", type=int, default=4, help="backward phases of the pipelined step: 2, 4, 5, or larger = one per stage")
     ap.add_argument("--single-graph", action="store_true", help="N = 1: the whole step as one HIP graph on one stream (through autograd)")
     ap.add_argument("--bucket-mb", type=int, default=64, help="largest single all-reduce message")
+    ap.add_argument("--wire", choices=("fp32", "bf16"), default="fp32",
+                    help="number format of the gradients on the links (bf16: half the bytes, one more rounding; see runtime/dp.py)")
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -333,7 +335,7 @@ def main():
         # data parallel: full replica per GPU; the decoder half of the flat gradient buffer is all-reduced (RCCL, AVG) while
         # the encoder half of the backward pass still runs, the encoder half right after it
         from dm_amd.runtime.dp import GradReducer
-        reducer = GradReducer(list(m.parameters()), 2 if rehearse else world, bucket_bytes=a.bucket_mb << 20)
+        reducer = GradReducer(list(m.parameters()), 2 if rehearse else world, bucket_bytes=a.bucket_mb << 20, wire=a.wire)
         reducer.broadcast_parameters()
         if a.no_overlap:
             step = graphs.GraphedTrainStep(m, crit, opt, x0, after_backward=reducer.allreduce, use_graph=not a.no_graph)
@@ -376,7 +378,8 @@ def main():
                                + (f", self-attention at stages {a.attention_stages}" if a.attention_stages else ""),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph,
                    "grad_exchange": ("none" if not dist else "one all-reduce after backward" if a.no_overlap else
-                                     "flat ranges of one gradient buffer: decoder half after the 2nd of 4 backward phases, the encoder's deep stages + latent after the 3rd, the small rest at the end; all but the last travel during the backward pass")},
+                                     "flat ranges of one gradient buffer: decoder half after the 2nd of 4 backward phases, the encoder's deep stages + latent after the 3rd, the small rest at the end; all but the last travel during the backward pass"),
+                   "grad_wire": a.wire if dist else None},
         "final_loss": loss,
     }
 
@@ -443,7 +446,7 @@ def main():
         if dist:
             from dm_amd.runtime.dp import GradReducer
             def rf(mm):
-                r_ = GradReducer(list(mm.parameters()), 2 if rehearse else world, bucket_bytes=a.bucket_mb << 20)
+                r_ = GradReducer(list(mm.parameters()), 2 if rehearse else world, bucket_bytes=a.bucket_mb << 20, wire=a.wire)
                 r_.broadcast_parameters()
                 return r_
         else:

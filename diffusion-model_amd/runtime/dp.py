@@ -29,11 +29,21 @@ def _pad4(n: int) -> int:
 
 
 class GradReducer:
-    def __init__(self, params: Sequence[Tensor], world: Optional[int] = None, *, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, params: Sequence[Tensor], world: Optional[int] = None, *, bucket_bytes: int = 64 << 20, group=None,
+                 wire: str = "fp32"):
+        """wire = "bf16": the gradients travel as bf16 (half the bytes on the links: 13.7 MB instead of 27.4 MB for the
+        denoiser) - each rank rounds its fp32 gradients to bf16 into a wire buffer, the collective sums / averages that
+        buffer, and the result is widened back into the fp32 gradient buffer, so every rank ends with the same fp32 values,
+        each exactly representable in bf16.  The sum itself is rounded to bf16 by the collective: one more rounding of
+        2^-9 relative per gradient than the fp32 wire, which Adam's normalisation by the running second moment absorbs; the
+        default stays fp32, which matches the reference's DistributedDataParallel bit for bit in what is summed."""
+        assert wire in ("fp32", "bf16"), wire
+        self.wire = wire
+        self._wire_buf: Optional[Tensor] = None
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = world if world is not None else td.get_world_size(group)
-        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.bucket_bytes = int(bucket_bytes)
         self.offs, total = [], 0
         for p in self.params:
             self.offs.append(total)
@@ -50,10 +60,13 @@ class GradReducer:
         return flat_grad_view(self.params, self.offs, self.total)
 
     def buckets(self, flat: Tensor) -> List[Tensor]:
-        n = flat.numel()
-        return [flat[i:min(n, i + self.bucket_elems)] for i in range(0, n, self.bucket_elems)]
+        n, step = flat.numel(), max(1, self.bucket_bytes // flat.element_size())
+        return [flat[i:min(n, i + step)] for i in range(0, n, step)]
 
     def _reduce(self, flat: Tensor) -> None:
+        if self.wire == "bf16":
+            self.finish(self.start_range(flat, 0, flat.numel()))
+            return
         op = td.ReduceOp.AVG if self._avg else td.ReduceOp.SUM
         works = [td.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets(flat)]
         for w in works:
@@ -70,16 +83,24 @@ class GradReducer:
             return None
         op = td.ReduceOp.AVG if self._avg else td.ReduceOp.SUM
         piece = flat[lo:hi]
-        return (piece, [td.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets(piece)])
+        if self.wire == "bf16":
+            if self._wire_buf is None or self._wire_buf.numel() != flat.numel() or self._wire_buf.device != flat.device:
+                self._wire_buf = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+            w = self._wire_buf[lo:hi]
+            w.copy_(piece)                        # round to nearest even, the same rounding the kernels use for activations
+            return (piece, [td.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets(w)], w)
+        return (piece, [td.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets(piece)], None)
 
     @torch.no_grad()
     def finish(self, handle) -> None:
         """Make the current stream wait for a start_range() exchange (host does not block on the GPU backend)."""
         if handle is None:
             return
-        piece, works = handle
+        piece, works, wire = handle
         for w in works:
             w.wait()
+        if wire is not None:
+            piece.copy_(wire)                     # bf16 -> fp32 is exact
         if not self._avg:
             piece.mul_(1.0 / self.world)
 

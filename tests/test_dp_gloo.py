@@ -101,6 +101,64 @@ def test_two_rank_gradient_exchange():
     assert all(r[2] and r[3] for r in res)
 
 
+def _grad_of_rank(n, rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    return torch.randn(n, generator=g) * torch.logspace(-6, 2, n)        # eight decades of magnitudes, like a network's gradients
+
+
+def _wire_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in SHAPES]
+        red = GradReducer(params, world, bucket_bytes=32, wire="bf16")     # 16 bf16 elements per collective
+        flat = torch.zeros(red.total)
+        for p, o in zip(params, red.offs):
+            p.grad = flat[o:o + p.numel()].view(p.shape)
+        flat.copy_(_grad_of_rank(red.total, rank))
+        assert len(red.buckets(flat.bfloat16())) > 1
+        # what every rank must end with: both ranks' gradients rounded to bf16, summed and rounded to bf16 once more (the
+        # collective's arithmetic type), widened to fp32 exactly, then halved in fp32
+        summed = (_grad_of_rank(red.total, 0).bfloat16() + _grad_of_rank(red.total, 1).bfloat16()).float() * 0.5
+        cut = red.offs[2]
+        h_hi = red.start_range(flat, cut, red.total)
+        h_lo = red.start_range(flat, 0, cut)
+        red.finish(h_hi)
+        red.finish(h_lo)
+        ok_range = torch.equal(flat, summed)
+        exact = torch.equal((flat * 2).bfloat16().float(), flat * 2)      # every value is a widened bf16 (times the exact 1/2)
+        flat.copy_(_grad_of_rank(red.total, rank))
+        red.allreduce()                                                    # the one-call path takes the same wire
+        ok_all = torch.equal(flat, summed) and all(p.grad.data_ptr() == flat[o:].data_ptr() for p, o in zip(params, red.offs))
+        fp32 = (_grad_of_rank(red.total, 0) + _grad_of_rank(red.total, 1)) * 0.5
+        rel = ((flat - fp32).abs() / fp32.abs().clamp_min(1e-30)).max().item()
+        q.put((rank, ok_range, exact, ok_all, rel, flat.clone()))
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_bf16_wire_format_reexpands_to_the_same_fp32_on_every_rank():
+    """The optional bf16 wire halves the bytes on the links; the fp32 gradients every rank ends with are bit-equal across
+    ranks, equal to the bf16-rounded sum widened exactly, and within three bf16 roundings (3 * 2^-9) of the fp32 exchange
+    wherever the two ranks' terms do not cancel."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wire_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] and r[3] for r in res), [(r[1], r[2], r[3]) for r in res]
+    assert torch.equal(res[0][5], res[1][5])
+    a, b = _grad_of_rank(res[0][5].numel(), 0), _grad_of_rank(res[0][5].numel(), 1)
+    fp32 = (a + b) * 0.5
+    bound = 3 * 2.0 ** -9 * (a.abs() + b.abs()) * 0.5
+    assert bool(((res[0][5] - fp32).abs() <= bound).all())
+
+
 def test_shard_range_covers_everything_once():
     for total in (0, 1, 7, 256, 1000):
         for world in (1, 2, 3, 8):
