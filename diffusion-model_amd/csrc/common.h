@@ -10,6 +10,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Global memory through a workgroup-uniform base (scalar registers) plus a 32-bit byte offset per lane: one address
+// register per access instead of a 64-bit pair, and no 64-bit vector arithmetic to form it.
+template <class T>
+__device__ __forceinline__ T ld_at(const void* base, unsigned byte_off) { return *(const T*)((const char*)base + byte_off); }
+template <class T>
+__device__ __forceinline__ void st_at(void* base, unsigned byte_off, const T& v) { *(T*)((char*)base + byte_off) = v; }
+
 #define DDPM_OK 0
 #define DDPM_EINVAL (-1)
 #define DDPM_EHIP (-2)
@@ -222,13 +229,16 @@ __device__ __forceinline__ void block_reduce_cols(float (&v)[8], int vps, float*
             for (int j = 0; j < 8; ++j) s_red[wave * 64 + lane * 8 + j] = v[j];
         }
         __syncthreads();
+        // waves added in ascending order (a fixed order: the sums are reproducible), two 16-byte reads per wave and only a
+        // few waves' reads in flight: fully unrolled scalar reads hold THREADS / 8 registers at once
         const int cv = lane % vps;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < THREADS / 64; ++w) a += s_red[w * 64 + cv * 8 + j];
-            v[j] = a;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int w = 0; w < THREADS / 64; ++w) {
+            lo += *(const f32x4*)(s_red + w * 64 + cv * 8);
+            hi += *(const f32x4*)(s_red + w * 64 + cv * 8 + 4);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
     }
 }

@@ -208,6 +208,10 @@ __device__ __forceinline__ void gn_bwd_body(const GnArgs& a) {
     const int cv = tid % vps, prow = tid / vps, pstep = THREADS / vps;
     const long long base = (long long)n * a.HW * a.C + c0 + cv * 8;
     const int cpg = a.G > 0 ? a.C / a.G : 1;
+    // the cached path addresses memory as a workgroup-uniform base (this image, this slab) plus a 32-bit byte offset per lane
+    const long long ubase = (long long)n * a.HW * a.C + c0;
+    const bf16* const xb = a.x + ubase; const bf16* const dyb = a.dy + ubase; bf16* const yb = a.y + ubase;
+    const unsigned char* const mb = a.mask ? a.mask + (ubase >> 3) : nullptr;
 
     float ga[8], be[8], mean[8], rstd[8];
 #pragma unroll
@@ -228,8 +232,7 @@ __device__ __forceinline__ void gn_bwd_body(const GnArgs& a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ab[j] = 0.f;
     // g and xhat of one vector; acc: also add this vector's terms of the activation scalar's gradient
-    auto gx = [&](const bf16x8& xv, const bf16x8& dv, long long e, float (&g)[8], float (&xh)[8], bool acc) {
-        const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
+    auto gx = [&](const bf16x8& xv, const bf16x8& dv, unsigned m, float (&g)[8], float (&xh)[8], bool acc) {
         const float ms = a.mask ? a.mask_scale : 1.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -254,34 +257,37 @@ __device__ __forceinline__ void gn_bwd_body(const GnArgs& a) {
     for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
     if constexpr (CACHED) {
         bf16x8 dc[GN_NV];
+        unsigned mc[GN_NV];
 #pragma unroll
         for (int k = 0; k < GN_NV; ++k) {
             const int p = prow + k * pstep;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { xc[k][j] = (bf16)0.f; dc[k][j] = (bf16)0.f; }
+            mc[k] = 0xFFu;                                   // (vectors past the last pixel are never read: every use is guarded)
             if (p < a.HW) {
-                xc[k] = *(const bf16x8*)(a.x + base + (long long)p * a.C);
-                dc[k] = *(const bf16x8*)(a.dy + base + (long long)p * a.C);
+                const unsigned e = (unsigned)(p * a.C + cv * 8);
+                xc[k] = ld_at<bf16x8>(xb, e * 2);
+                dc[k] = ld_at<bf16x8>(dyb, e * 2);
+                if (mb) mc[k] = ld_at<unsigned char>(mb, e >> 3);
             }
         }
 #pragma unroll
         for (int k = 0; k < GN_NV; ++k) {
             const int p = prow + k * pstep;
             float xh[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gc[k][j] = 0.f;
             if (p < a.HW) {
-                gx(xc[k], dc[k], base + (long long)p * a.C, gc[k], xh, true);
+                gx(xc[k], dc[k], mc[k], gc[k], xh, true);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { a1[j] += gc[k][j]; a2[j] += gc[k][j] * xh[j]; }
             }
         }
+        // x stays packed (bf16) across the reductions below; otherwise its fp32 copies are kept for the second pass as well
+#pragma unroll
+        for (int k = 0; k < GN_NV; ++k) asm volatile("" : "+v"(xc[k]));
     } else if (a.G > 0) {
 #pragma unroll 2
         for (int p = prow; p < a.HW; p += pstep) {
             const long long e = base + (long long)p * a.C;
             float g[8], xh[8];
-            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh, true);
+            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), a.mask ? a.mask[e >> 3] : 0xFFu, g, xh, true);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; }
         }
@@ -331,7 +337,7 @@ __device__ __forceinline__ void gn_bwd_body(const GnArgs& a) {
                     db[j] += dx;
                     w[j] = (bf16)dx;
                 }
-                *(bf16x8*)(a.y + base + (long long)p * a.C) = w;
+                st_at(yb, (unsigned)(p * a.C + cv * 8) * 2, w);
             }
         }
     } else {
@@ -339,7 +345,7 @@ __device__ __forceinline__ void gn_bwd_body(const GnArgs& a) {
         for (int p = prow; p < a.HW; p += pstep) {
             const long long e = base + (long long)p * a.C;
             float g[8], xh[8];
-            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), e, g, xh, a.G == 0);   // without a norm this is the only pass
+            gx(*(const bf16x8*)(a.x + e), *(const bf16x8*)(a.dy + e), a.mask ? a.mask[e >> 3] : 0xFFu, g, xh, a.G == 0);   // without a norm this is the only pass
             bf16x8 w;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -530,10 +536,11 @@ __device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, 
         }
     }
 }
-// ab != nullptr: also adds this vector's terms of the activation scalar's gradient
+// with_ab: also adds this vector's terms of the activation scalar's gradient to ab (an array by reference: a pointer that
+// may be null would put the caller's array in scratch memory)
 template <int A>
 __device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, long long e, float (&g)[8], float (&xh)[8], float (&xf)[8],
-                                          float* ab = nullptr) {
+                                          float (&ab)[8], bool with_ab) {
     const bf16x8 xv = *(const bf16x8*)(a.x + e), dv = *(const bf16x8*)(a.dy + e);
     const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
     const float ms = a.mask ? a.mask_scale : 1.f;
@@ -545,7 +552,7 @@ __device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, l
         const float gg = (float)dv[j] * act_bwd(z, GN_ACT(A, a), L.bsc) * ms;
         g[j] = (m >> j) & 1 ? gg : 0.f;
         if constexpr (A < 0)
-            if (ab) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
+            if (with_ab) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
     }
 }
 
@@ -574,7 +581,7 @@ __device__ __forceinline__ void gn_bwd_split_sums_body(const GnArgs& a) {
 #pragma unroll 2
     for (int r = r0 + prow; r < r1; r += pstep) {
         float g[8], xh[8], xf[8];
-        gn_bwd_gx<A>(a, L, base + (long long)r * a.C, g, xh, xf, hb ? ab : nullptr);
+        gn_bwd_gx<A>(a, L, base + (long long)r * a.C, g, xh, xf, ab, hb);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
     }
@@ -657,8 +664,8 @@ __device__ __forceinline__ void gn_bwd_split_apply_body(const GnArgs& a) {
 #pragma unroll 2
     for (int r = r0 + prow; r < r1; r += pstep) {
         const long long e = base + (long long)r * a.C;
-        float g[8], xh[8], xf[8];
-        gn_bwd_gx<A>(a, L, e, g, xh, xf);
+        float g[8], xh[8], xf[8], none[8];
+        gn_bwd_gx<A>(a, L, e, g, xh, xf, none, false);
         bf16x8 w;
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = (bf16)(L.rstd[j] * (L.ga[j] * g[j] - (S1[j] + xh[j] * S2[j])));

@@ -130,7 +130,8 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * IPW;
     const long long row0 = (long long)n0 * HW;    // first global pixel row of this workgroup
-    const int rows_valid = min(M, (a.N - n0) * HW);
+    const int rows_valid = IPW == 1 ? M : min(M, (a.N - n0) * HW);
+    auto live = [&](int row) { return IPW == 1 || row < rows_valid; };      // one image per workgroup: never ragged, the row checks fold away
     const bool rec = a.raw_e != nullptr;
 
     SIR_STAMP(0);
@@ -149,7 +150,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         const int row = r1 + k * E1::RPP;
         const long long e = (row0 + row) * E + v1 * 8;
         mk_e[k] = mk_d[k] = 0xFFu;
-        if (a.m_e && row < rows_valid) { mk_e[k] = a.m_e[e >> 3]; mk_d[k] = a.m_d[e >> 3]; }
+        if (a.m_e && live(row)) { mk_e[k] = a.m_e[e >> 3]; mk_d[k] = a.m_d[e >> 3]; }
     }
     bf16x8 rx[E3::NV];                            // clean block input for the residual
 #pragma unroll
@@ -157,7 +158,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         const int row = r3 + k * E3::RPP;
 #pragma unroll
         for (int j = 0; j < 8; ++j) rx[k][j] = (bf16)0.f;
-        if (row < rows_valid) rx[k] = *(const bf16x8*)(a.x + (row0 + row) * C + v3 * 8);
+        if (live(row)) rx[k] = *(const bf16x8*)(a.x + (row0 + row) * C + v3 * 8);
     }
     constexpr int MT = MR / 32;
     bf16x8 bfrag1[GemmK<C>::KCH];                 // first weight chunk of this wave's first expansion tile
@@ -169,7 +170,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
-        if (row < rows_valid) {
+        if (live(row)) {
             const long long e = (row0 + row) * C + cv * 8;
             v = *(const bf16x8*)(a.x + e);
             if (a.m_in) {
@@ -213,7 +214,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
 #pragma unroll
         for (int k = 0; k < E1::NV; ++k) {
             const int row = r1 + k * E1::RPP;
-            if (raw_out && row < rows_valid) *(bf16x8*)(raw_out + (row0 + row) * E + v1 * 8) = xr[k];
+            if (raw_out && live(row)) *(bf16x8*)(raw_out + (row0 + row) * E + v1 * 8) = xr[k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)xr[k][j]; s[j] += f; ss[j] += f * f; }
             if constexpr (IPW > 1) {
@@ -225,6 +226,9 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         SIR_STAMP(10);
         if constexpr (IPW == 1) group_store<E, M>(s, ss, wave, v1, lane, s_part);
         SIR_STAMP(11);
+        // the tile stays packed (bf16) across the barriers; otherwise the fp32 copies made for the sums are kept alive
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) asm volatile("" : "+v"(xr[k]));
         __syncthreads();
         SIR_STAMP(12);
         group_finish<E, M, HW, IPW>(tid, s_part, s_mr, a.eps, st_out, n0, a.N);
@@ -253,7 +257,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
                 o[j] = (bf16)z;
             }
             *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
-            if (y_out && row < rows_valid) *(bf16x8*)(y_out + e) = o;
+            if (y_out && live(row)) *(bf16x8*)(y_out + e) = o;
         }
     };
 
@@ -338,7 +342,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
             const int row = r3 + k * E3::RPP;
             xo[k] = *(const bf16x8*)(s_x + row * XS + v3 * 16);
             const long long e = (row0 + row) * C + v3 * 8;
-            if (rec && row < rows_valid) *(bf16x8*)(a.raw_o + e) = xo[k];
+            if (rec && live(row)) *(bf16x8*)(a.raw_o + e) = xo[k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
             if constexpr (IPW > 1) {
@@ -357,7 +361,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
 #pragma unroll
         for (int k = 0; k < E3::NV; ++k) {
             const int row = r3 + k * E3::RPP;
-            if (row >= rows_valid) continue;
+            if (!live(row)) continue;
             const int img = IPW > 1 ? row / HW : 0;
             bf16x8 o;
 #pragma unroll
@@ -425,6 +429,15 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
     const long long n0 = blockIdx.x;
     const long long row0 = n0 * HW;
     const bool rec = a.raw_e != nullptr;
+    // workgroup-uniform bases of this image's rows; lanes add 32-bit byte offsets (ld_at / st_at)
+    const bf16* const xb = a.x + row0 * C;
+    bf16* const yb = a.y + row0 * C;
+    bf16* const raw_eb = a.raw_e + row0 * E; bf16* const y_eb = a.y_e + row0 * E;
+    bf16* const raw_db = a.raw_d + row0 * E; bf16* const y_db = a.y_d + row0 * E;
+    bf16* const raw_ob = a.raw_o + row0 * C;
+    const unsigned char* const m_inb = a.m_in + (row0 * C >> 3);
+    const unsigned char* const m_eb = a.m_e + (row0 * E >> 3);
+    const unsigned char* const m_db = a.m_d + (row0 * E >> 3);
 
     for (int i = tid; i < E; i += SIR_THREADS) {
         s_p[P_BE + i] = a.be[i]; s_p[P_G1 + i] = a.g1[i]; s_p[P_B1 + i] = a.b1[i];
@@ -441,10 +454,10 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
         for (int i = 0; i < TPW; ++i)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const long long e = (row0 + (wave + NWV * i) * 32 + (lane & 31)) * C + ks * 16 + (lane >> 5) * 8;
-                bf16x8 v = *(const bf16x8*)(a.x + e);
+                const unsigned e = (unsigned)(((wave + NWV * i) * 32 + (lane & 31)) * C + ks * 16 + (lane >> 5) * 8);
+                bf16x8 v = ld_at<bf16x8>(xb, e * 2);
                 if (a.m_in) {
-                    const unsigned m = a.m_in[e >> 3];
+                    const unsigned m = ld_at<unsigned char>(m_inb, e >> 3);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = (m >> j) & 1 ? (bf16)((float)v[j] * a.mscale) : (bf16)0.f;
                 }
@@ -484,11 +497,15 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
 #pragma unroll
         for (int k = 0; k < E1::NV; ++k) {
             const int row = r1 + k * E1::RPP;
-            if (raw_out) *(bf16x8*)(raw_out + (row0 + row) * E + v1 * 8) = xr[k];
+            if (raw_out) st_at(raw_out, (unsigned)(row * E + v1 * 8) * 2, xr[k]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)xr[k][j]; s[j] += f; ss[j] += f * f; }
         }
         group_store<E, M>(s, ss, wave, v1, lane, s_part);
+        // the tile stays packed (bf16) across the barriers: without this the fp32 copies made for the sums above are kept
+        // for the normalisation below, 128 registers of them
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) asm volatile("" : "+v"(xr[k]));
         __syncthreads();
         group_finish<E, M, HW, 1>(tid, s_part, s_mr, a.eps, st_out, n0, a.N);
         __syncthreads();
@@ -503,7 +520,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
         }
         unsigned mk[E1::NV];
 #pragma unroll
-        for (int k = 0; k < E1::NV; ++k) mk[k] = mask ? mask[((row0 + r1 + k * E1::RPP) * E + v1 * 8) >> 3] : 0xFFu;
+        for (int k = 0; k < E1::NV; ++k) mk[k] = mask ? ld_at<unsigned char>(mask, (unsigned)((r1 + k * E1::RPP) * E + v1 * 8) >> 3) : 0xFFu;
 #pragma unroll
         for (int k = 0; k < E1::NV; ++k) {
             const int row = r1 + k * E1::RPP;
@@ -516,14 +533,14 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
             }
             asm volatile("" : "+v"(o));                    // one vector after the other: interleaved activation chains spill
             *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
-            if (y_out) *(bf16x8*)(y_out + (row0 + row) * E + v1 * 8) = o;
+            if (y_out) st_at(y_out, (unsigned)(row * E + v1 * 8) * 2, o);
         }
     };
 
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) xr[k] = *(const bf16x8*)(s_e + (r1 + k * E1::RPP) * ES + v1 * 16);
-    stats_phase(rec ? a.raw_e : nullptr, rec ? a.st1 : nullptr);
-    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e, rec ? a.y_e : nullptr);
+    stats_phase(rec ? raw_eb : nullptr, rec ? a.st1 : nullptr);
+    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e ? m_eb : nullptr, rec ? y_eb : nullptr);
     __syncthreads();
 
     // ---- depthwise 3x3 from the LDS tile, four vectors at a time (accumulator registers)
@@ -571,8 +588,8 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
     bf16x8 bf2[E / 16];                            // projection weights of this lane's output channel (one N tile)
 #pragma unroll
     for (int ks = 0; ks < E / 16; ++ks) bf2[ks] = *(const bf16x8*)(a.wp + (long long)(lane & 31) * E + ks * 16 + (lane >> 5) * 8);
-    stats_phase(rec ? a.raw_d : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
-    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e ? a.m_d : nullptr, rec ? a.y_d : nullptr);
+    stats_phase(rec ? raw_db : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
+    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e ? m_db : nullptr, rec ? y_db : nullptr);
     __syncthreads();
 
     // ---- project: all of this wave's tiles stay in accumulators until every wave has read the expanded tile
@@ -612,14 +629,14 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
         for (int k = 0; k < E3::NV; ++k) {
             const int row = r3 + k * E3::RPP;
             xo[k] = *(const bf16x8*)(s_e + row * XS + v3 * 16);
-            if (rec) *(bf16x8*)(a.raw_o + (row0 + row) * C + v3 * 8) = xo[k];
+            if (rec) st_at(raw_ob, (unsigned)(row * C + v3 * 8) * 2, xo[k]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
         }
         group_store<C, M>(s, ss, wave, v3, lane, s_part);
         bf16x8 rx[E3::NV];
 #pragma unroll
-        for (int k = 0; k < E3::NV; ++k) rx[k] = *(const bf16x8*)(a.x + (row0 + r3 + k * E3::RPP) * C + v3 * 8);
+        for (int k = 0; k < E3::NV; ++k) rx[k] = ld_at<bf16x8>(xb, (unsigned)((r3 + k * E3::RPP) * C + v3 * 8) * 2);
         __syncthreads();
         group_finish<C, M, HW, 1>(tid, s_part, s_mr, a.eps, rec ? a.st3 : nullptr, n0, a.N);
         __syncthreads();
@@ -636,7 +653,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)xo[k][j] * sc[j] + sh[j] + (float)rx[k][j]);
-            *(bf16x8*)(a.y + (row0 + row) * C + v3 * 8) = o;
+            st_at(yb, (unsigned)(row * C + v3 * 8) * 2, o);
         }
     }
 }

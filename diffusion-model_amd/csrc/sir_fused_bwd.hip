@@ -214,8 +214,15 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long n0 = (long long)blockIdx.x * IPW;
     const long long row0 = n0 * HW;
-    const int rows_valid = (int)min((long long)M, (a.N - n0) * HW);
+    const int rows_valid = IPW == 1 ? M : (int)min((long long)M, (a.N - n0) * HW);
+    auto live = [&](int row) { return IPW == 1 || row < rows_valid; };      // one image per workgroup: never ragged, the row checks fold away
     const bool use_mask = a.m_e != nullptr;
+    // workgroup-uniform bases of this workgroup's rows; lanes add 32-bit byte offsets (ld_at / st_at)
+    const bf16* const dyb = a.dy + row0 * C; const bf16* const raw_ob = a.raw_o + row0 * C;
+    const bf16* const raw_eb = a.raw_e + row0 * E; const bf16* const raw_db = a.raw_d + row0 * E; const bf16* const y_eb = a.y_e + row0 * E;
+    const unsigned char* const m_inb = a.m_in + (row0 * C >> 3);
+    const unsigned char* const m_eb = a.m_e + (row0 * E >> 3); const unsigned char* const m_db = a.m_d + (row0 * E >> 3);
+    bf16* const dxb = a.dx + row0 * C; bf16* const d_ob = a.d_o + row0 * C; bf16* const d_eb = a.d_e + row0 * E;
 
     SIRB_STAMP(0);
     // ---- one round trip for everything small
@@ -230,20 +237,19 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
         s_mr[i] = (n0 + rem / (2 * SIR_G) < a.N) ? st[n0 * 2 * SIR_G + rem] : 0.f;
     }
     const int v1 = tid % E1::VPR, r1 = tid / E1::VPR;
-    const int v3 = tid % E3::VPR, r3 = tid / E3::VPR;
+    const int v3a = tid % E3::VPR, r3a = tid / E3::VPR;
     bf16x8 dyv[E3::NV], rawo[E3::NV];
-    unsigned mk_in[E3::NV], mk_none3[E3::NV];
+    unsigned mk_none3[E3::NV];
 #pragma unroll
     for (int k = 0; k < E3::NV; ++k) {
-        const int row = r3 * E3::NV + k;
-        const long long e = (row0 + row) * C + v3 * 8;
+        const int row = r3a * E3::NV + k;
+        const unsigned e = (unsigned)(row * C + v3a * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dyv[k][j] = (bf16)0.f; rawo[k][j] = (bf16)0.f; }
-        mk_in[k] = 0xFFu; mk_none3[k] = 0xFFu;
-        if (row < rows_valid) {
-            dyv[k] = *(const bf16x8*)(a.dy + e);
-            rawo[k] = *(const bf16x8*)(a.raw_o + e);
-            if (a.m_in) mk_in[k] = a.m_in[e >> 3];
+        mk_none3[k] = 0xFFu;
+        if (live(row)) {
+            dyv[k] = ld_at<bf16x8>(dyb, e * 2);
+            rawo[k] = ld_at<bf16x8>(raw_ob, e * 2);
         }
     }
     bf16x8 rawd[E1::NV];
@@ -251,13 +257,13 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) {
         const int row = r1 * E1::NV + k;
-        const long long e = (row0 + row) * E + v1 * 8;
+        const unsigned e = (unsigned)(row * E + v1 * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) rawd[k][j] = (bf16)0.f;
         mk_e[k] = mk_d[k] = 0xFFu;
-        if (row < rows_valid) {
-            rawd[k] = *(const bf16x8*)(a.raw_d + e);
-            if (use_mask) { mk_e[k] = a.m_e[e >> 3]; mk_d[k] = a.m_d[e >> 3]; }
+        if (live(row)) {
+            rawd[k] = ld_at<bf16x8>(raw_db, e * 2);
+            if (use_mask) mk_d[k] = ld_at<unsigned char>(m_db, e >> 3);
         }
     }
     bf16x8 bfrag1[GemmK<C>::KCH];
@@ -276,12 +282,12 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
                                             a.part3, n0, a.N, tid);
 #pragma unroll
         for (int k = 0; k < E3::NV; ++k) {
-            const int row = r3 * E3::NV + k;
+            const int row = r3a * E3::NV + k;
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16)g[k][j];
-            *(bf16x8*)(s_x + row * XS + v3 * 16) = o;
-            if (row < rows_valid) *(bf16x8*)(a.d_o + (row0 + row) * C + v3 * 8) = o;
+            *(bf16x8*)(s_x + row * XS + v3a * 16) = o;
+            if (live(row)) st_at(d_ob, (unsigned)(row * C + v3a * 8) * 2, o);
         }
     }
     __syncthreads();
@@ -318,15 +324,30 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     norm_bwd<E, M, HW, IPW, E, ACT>(rawd, g, mk_d, use_mask, a.mscale, s_p + P_G2, s_p + P_B2, s_mr + IPW * 2 * SIR_G, s_col, s_grp, a.part2,
                                    n0, a.N, tid);
     // the forward activation feeding the depthwise conv and the raw expansion output are needed next: request them now
+    // (the widest tile has no registers to spare for the raw values during the depthwise phase: it asks for them afterwards)
+    constexpr bool RAW_E_LATE = E1::NV * E >= 1024;
     bf16x8 yev[E1::NV], rawe[E1::NV];
+    auto load_raw_e = [&](int r1, int v1) {
+#pragma unroll
+        for (int k = 0; k < E1::NV; ++k) {
+            const int row = r1 * E1::NV + k;
+            const unsigned e = (unsigned)(row * E + v1 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rawe[k][j] = (bf16)0.f;
+            if (live(row)) {
+                rawe[k] = ld_at<bf16x8>(raw_eb, e * 2);
+                if (use_mask) mk_e[k] = ld_at<unsigned char>(m_eb, e >> 3);
+            }
+        }
+    };
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) {
         const int row = r1 * E1::NV + k;
-        const long long e = (row0 + row) * E + v1 * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { yev[k][j] = (bf16)0.f; rawe[k][j] = (bf16)0.f; }
-        if (row < rows_valid) { yev[k] = *(const bf16x8*)(a.y_e + e); rawe[k] = *(const bf16x8*)(a.raw_e + e); }
+        for (int j = 0; j < 8; ++j) yev[k][j] = (bf16)0.f;
+        if (live(row)) yev[k] = ld_at<bf16x8>(y_eb, (unsigned)(row * E + v1 * 8) * 2);
     }
+    if constexpr (!RAW_E_LATE) load_raw_e(r1, v1);
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) {
         bf16x8 o;
@@ -397,20 +418,26 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
 
     SIRB_STAMP(5);
     // ---- first GroupNorm + activation + dropout backward -> d_e
+    // (thread indices formed again from an opaque copy: the addresses of this phase are then computed here, not carried -
+    // in registers the wide tiles do not have - from the phase above that used the same ones)
+    int tid1 = tid;
+    asm volatile("" : "+v"(tid1));
+    const int v1b = tid1 % E1::VPR, r1b = tid1 / E1::VPR;
+    if constexpr (RAW_E_LATE) load_raw_e(r1b, v1b);
     bf16x8 bfrag2[GemmK<E>::KCH];
     if (wave < MT * (C / 32)) gemm_prefetch<E>(bfrag2, a.wed + (long long)((wave / MT) * 32 + (lane & 31)) * E, lane);
-    norm_bwd<E, M, HW, IPW, E, ACT>(rawe, g, mk_e, use_mask, a.mscale, s_p + P_G1, s_p + P_B1, s_mr, s_col + 0, s_grp, a.part1, n0, a.N, tid);
+    norm_bwd<E, M, HW, IPW, E, ACT>(rawe, g, mk_e, use_mask, a.mscale, s_p + P_G1, s_p + P_B1, s_mr, s_col + 0, s_grp, a.part1, n0, a.N, tid1);
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) {
-        const int row = r1 * E1::NV + k;
+        const int row = r1b * E1::NV + k;
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (bf16)g[k][j];
-        *(bf16x8*)(s_e + row * ES + v1 * 16) = o;
-        if (row < rows_valid) *(bf16x8*)(a.d_e + (row0 + row) * E + v1 * 8) = o;
+        *(bf16x8*)(s_e + row * ES + v1b * 16) = o;
+        if (live(row)) st_at(d_eb, (unsigned)(row * E + v1b * 8) * 2, o);
     }
     __syncthreads();
-    col2_flush<E, IPW, E>(s_col, a.part1, n0, a.N, tid);
+    col2_flush<E, IPW, E>(s_col, a.part1, n0, a.N, tid1);
 
     SIRB_STAMP(6);
     // ---- expansion data-gradient: [M][E] x [C][E]^T -> LDS (bf16)
@@ -429,6 +456,23 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
             }
         }
     }
+    // the incoming gradient and the input's dropout bits again (L2 hits, in flight across the barrier): cheaper than
+    // holding them in registers through every phase above
+    bf16x8 dy2[E3::NV];
+    unsigned mk_in[E3::NV];
+    int tid_end = tid;
+    asm volatile("" : "+v"(tid_end));              // the row / vector indices are formed again here rather than kept (or spilled) since the first phase
+    const int v3 = tid_end % E3::VPR, r3 = tid_end / E3::VPR;
+#pragma unroll
+    for (int k = 0; k < E3::NV; ++k) {
+        const int row = r3 * E3::NV + k;
+        const unsigned e = (unsigned)(row * C + v3 * 8);
+        mk_in[k] = 0xFFu;
+        if (live(row)) {
+            dy2[k] = ld_at<bf16x8>(dyb, e * 2);
+            if (a.m_in) mk_in[k] = ld_at<unsigned char>(m_inb, e >> 3);
+        }
+    }
     __syncthreads();
 
     SIRB_STAMP(7);
@@ -436,16 +480,16 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
 #pragma unroll
     for (int k = 0; k < E3::NV; ++k) {
         const int row = r3 * E3::NV + k;
-        if (row >= rows_valid) continue;
+        if (!live(row)) continue;
         const bf16x8 t = *(const bf16x8*)(s_x + row * XS + v3 * 16);
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float d = (float)t[j];
             if (a.m_in) d = (mk_in[k] >> j) & 1 ? (float)(bf16)(d * a.mscale) : 0.f;
-            o[j] = (bf16)(d + (float)dyv[k][j]);
+            o[j] = (bf16)(d + (float)dy2[k][j]);
         }
-        *(bf16x8*)(a.dx + (row0 + row) * C + v3 * 8) = o;
+        st_at(dxb, (unsigned)(row * C + v3 * 8) * 2, o);
     }
     SIRB_STAMP(8);
 }
@@ -842,23 +886,26 @@ static int sir_bwd_big_launch(const SirBwdArgs& a, hipStream_t stream) {
     return ddpm_check_launch("sir_backward");
 }
 
-template <int C, int W>
-__global__ __launch_bounds__(SIR_THREADS) void sir_bwd_kernel(const SirBwdArgs a) {
+// The activation is a template argument of the kernel (not a switch inside it): each activation's body is then
+// register-allocated on its own, and the widest shape needs no scratch memory.
+// Waves per SIMD the register allocation must leave room for.  The narrow tiles land within a few registers of 128, the
+// limit under which two workgroups share a CU: with GELU (the reference's default) they are held to it, which costs no
+// scratch memory; the other activations keep their natural allocation (122 - 134 registers).
+constexpr int sir_bwd_waves(int c, int w, int act) { return (c * w <= 512 && w <= 8 && act == ACT_GELU) ? 4 : 2; }
+
+template <int C, int W, int ACT>
+__global__ __launch_bounds__(SIR_THREADS, sir_bwd_waves(C, W, ACT)) void sir_bwd_kernel(const SirBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    switch (a.act) {
-        case ACT_GELU: sir_bwd_body<C, W, ACT_GELU>(a, smem); break;
-        case ACT_SILU: sir_bwd_body<C, W, ACT_SILU>(a, smem); break;
-        default: sir_bwd_body<C, W, ACT_RELU>(a, smem); break;
-    }
+    sir_bwd_body<C, W, ACT>(a, smem);
 }
 
-template <int C, int W>
-static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
+template <int C, int W, int ACT>
+static int sir_bwd_launch_act(const SirBwdArgs& a, hipStream_t stream) {
     constexpr int E = 2 * C, HW = W * W, IPW = sir_ipw(HW), M = sir_tile_rows(IPW * HW);
     constexpr int lds = M * (C * 2 + 16) + M * (E * 2 + 16) +
                         (3 * (SIR_THREADS / 64) * E + IPW * 2 * SIR_G + 3 * IPW * 2 * SIR_G + 13 * E + C) * 4;
     static_assert(lds <= 160 * 1024, "tiles do not fit LDS");
-    auto k = sir_bwd_kernel<C, W>;
+    auto k = sir_bwd_kernel<C, W, ACT>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -869,6 +916,15 @@ static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
     }
     hipLaunchKernelGGL(k, dim3((a.N + IPW - 1) / IPW), dim3(SIR_THREADS), lds, stream, a);
     return ddpm_check_launch("sir_backward");
+}
+
+template <int C, int W>
+static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
+    switch (a.act) {
+        case ACT_GELU: return sir_bwd_launch_act<C, W, ACT_GELU>(a, stream);
+        case ACT_SILU: return sir_bwd_launch_act<C, W, ACT_SILU>(a, stream);
+        default: return sir_bwd_launch_act<C, W, ACT_RELU>(a, stream);
+    }
 }
 
 extern "C" int ddpm_sir_workgroups(int HW, int N) {

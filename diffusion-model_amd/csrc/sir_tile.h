@@ -30,6 +30,7 @@ struct Ew {
     static constexpr int CPG = CH / SIR_G;                   // channels per group
     static constexpr int GPV = CPG >= 8 ? 1 : 8 / CPG;       // groups inside one vector
     static constexpr int VPG = CPG >= 8 ? CPG / 8 : 1;       // vectors spanning one group
+    typedef bf16x8 Vecs[NV];                                 // the vectors one thread holds
     static_assert(NV >= 1 && VPR <= 64 && (SIR_THREADS % VPR) == 0, "unsupported tile shape");
 };
 
