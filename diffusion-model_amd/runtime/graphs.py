@@ -30,7 +30,7 @@ def _pool_stream(device, k: int = 0) -> "torch.cuda.Stream":
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _STREAM_POOL:
-        _STREAM_POOL[key] = [torch.cuda.Stream(device=key) for _ in range(3)]
+        _STREAM_POOL[key] = [torch.cuda.Stream(device=key) for _ in range(4)]
     pool = _STREAM_POOL[key]
     while k >= len(pool):
         pool.append(torch.cuda.Stream(device=key))
@@ -149,7 +149,7 @@ class PipelinedTrainStep:
     engine's persistent flat gradient buffer.  Copy a new batch into `self.x0` before each replay()."""
 
     def __init__(self, ddpm, criterion, optimizer, x0: Tensor, reducer=None, *, phases: int = 4, use_graph: bool = True, warmup: int = 3,
-                 gradient_accumulation_steps=1, t: Optional[Tensor] = None, noise: Optional[Tensor] = None):
+                 gradient_accumulation_steps=1, t: Optional[Tensor] = None, noise: Optional[Tensor] = None, side_stream=None):
         """gradient_accumulation_steps = k > 1 (the reference trainer's default is 3, base_trainer.py:43,215-235 there):
         gradients of k consecutive replays are summed without any 1/k scaling, the optimizer steps on every k-th replay
         (or on replay(last=True), the trainer's "last batch of the epoch" case) and the sum restarts after it; with a
@@ -195,7 +195,7 @@ class PipelinedTrainStep:
         self._bound = False
         self._handles = []
         self.graphs = None
-        self.side = _pool_stream(x0.device, 0)
+        self.side = side_stream if side_stream is not None else _pool_stream(x0.device, 0)
         self.events = [torch.cuda.Event() for _ in range(self.K)]
         self.ev_done = torch.cuda.Event()
         s = torch.cuda.Stream()
