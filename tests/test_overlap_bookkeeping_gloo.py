@@ -73,8 +73,8 @@ class _LoggingReducer(GradReducer):
         return super().start_range(flat, lo, hi) + ((lo, hi),)
 
     def finish(self, handle):
-        self.log.append(("finish",) + handle[2])
-        super().finish(handle[:2])
+        self.log.append(("finish",) + handle[-1])
+        super().finish(handle[:-1])
 
 
 def _drive(rank, ready_at_mid, final, enc_split=None):
