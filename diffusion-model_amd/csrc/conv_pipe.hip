@@ -278,6 +278,8 @@ extern "C" int ddpm_conv_pipe_mode(int mode) {
     return prev;
 }
 
+int ddpm_conv_pipe_mode_now() { return g_pipe_mode; }
+
 // Returns 1 when the problem was launched here, 0 when the caller should use another kernel, < 0 on error.
 int ddpm_conv_pipe_try(const ddpm_conv_desc* d, hipStream_t stream) {
     if (g_pipe_mode < 0) return 0;

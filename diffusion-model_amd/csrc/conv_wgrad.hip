@@ -499,7 +499,11 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     return DDPM_OK;
 }
 
+int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d);                    // conv_wgrad_pipe.hip
+int ddpm_conv_wgrad_pipe_try(const ddpm_wgrad_desc* d, hipStream_t stream);
+
 extern "C" int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d) {
+    if (const int s = ddpm_conv_wgrad_pipe_splits(d)) return s;
     WgradPlan p;
     ddpm_wgrad_desc tmp = *d;
     if (!tmp.dw && !tmp.part) tmp.part = (float*)16;        // sizing query: output pointers are not needed yet
@@ -510,7 +514,8 @@ extern "C" int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d) {
 extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WgradPlan p;
-    if (int rc = wgrad_plan(d, p)) return rc;
+    if (int rc = wgrad_plan(d, p)) return rc;            // (also validates the descriptor)
+    if (const int rc = ddpm_conv_wgrad_pipe_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
     if (p.pointwise) {
         static bool attr = false;
         if (!attr) {

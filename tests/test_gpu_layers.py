@@ -158,6 +158,36 @@ def test_conv_wgrad(dev, kind, n, ci, co, h, w_):
     assert_rel(unpack_dw(kind, dwk.cpu(), co, ci), 2 * gw, 5e-3)
 
 
+@pytest.mark.parametrize("n,ci,co,w_", [(16, 64, 128, 8), (32, 128, 128, 4), (9, 64, 256, 16), (40, 128, 256, 8), (64, 192, 128, 4), (8, 64, 128, 16),
+                                         (160, 256, 256, 8), (24, 128, 256, 16), (512, 256, 256, 4)])
+def test_conv_wgrad_pipelined_kernel(dev, n, ci, co, w_):
+    """The pipelined weight-gradient kernel (128 x 64 channel tiles, all nine taps in accumulators, two LDS stages), forced
+    onto small problems: atomics into dw, and per-split partial blocks folded on the host, against torch fp32 on the same
+    bf16 operands and against the tap-list kernel."""
+    w = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    x = r16(hash_normal((n, ci, w_, w_), 3))
+    ref = torch_ref(hip.CONV_3X3_S1, x, w, None)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    (gw,) = torch.autograd.grad(ref, w, gy)
+    xd, gd = nhwc(x, dev), nhwc(gy, dev)
+    old = torch.zeros(9, co, ci, device=dev)
+    prev = hip.lib().ddpm_conv_pipe_mode(-1)
+    try:
+        ops.conv_wgrad(hip.CONV_3X3_S1, xd, gd, co, old)
+        hip.lib().ddpm_conv_pipe_mode(1)
+        splits = ops.conv_wgrad_splits(hip.CONV_3X3_S1, xd, gd, co)
+        assert splits % 8 == 0 and splits >= 8, splits               # (the tap-list kernel's count is not a multiple of 8 for these sizes)
+        dwk = torch.zeros(9, co, ci, device=dev)
+        ops.conv_wgrad(hip.CONV_3X3_S1, xd, gd, co, dwk)
+        part = torch.full((splits, 9, co, ci), float("nan"), device=dev)
+        ops.conv_wgrad(hip.CONV_3X3_S1, xd, gd, co, None, part=part)
+    finally:
+        hip.lib().ddpm_conv_pipe_mode(prev)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, dwk.cpu(), co, ci), gw, 5e-3)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, part.sum(0).cpu(), co, ci), gw, 5e-3)
+    assert_rel(dwk.cpu(), old.cpu(), 1e-4)                           # same bf16 products, fp32 sums in another order
+
+
 def test_conv_wgrad_fused_input(dev):
     n, c0, c1, co, h = 3, 64, 64, 64, 8
     x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))

@@ -53,7 +53,7 @@ def run_case(cin, cout, w, n, what, kernel, reps):
         us = e0.elapsed_time(e1) * 1e3 / reps
     finally:
         hip.lib().ddpm_conv_pipe_mode(prev)
-    return {"cin": cin, "cout": cout, "image": f"{w}x{w}", "batch": n, "what": what, "kernel": kernel, "kernel_used": hip.CONV_KERNEL_NAMES.get(used, "conv_wgrad_kernel"),
+    return {"cin": cin, "cout": cout, "image": f"{w}x{w}", "batch": n, "what": what, "kernel": kernel, "kernel_used": hip.CONV_KERNEL_NAMES.get(used, "conv_wgrad_pipe_kernel" if kernel == "pipe" else "conv_wgrad_kernel"),
             "us": us, "gflop": flops * 1e-9, "tflops": flops / us * 1e-6, "frac_of_2500_tflops": flops / us * 1e-6 / 2500.0}
 
 
@@ -69,7 +69,7 @@ def main():
     rows = []
     for cin, cout, w in ((128, 128, 16), (256, 256, 8), (256, 512, 4), (512, 256, 4)):
         for n in ((1024, 4096) if w == 16 else (4096, 16384) if w == 8 else (16384, 65536)):
-            for what in ("fwd", "dgrad"):
+            for what in ("fwd", "dgrad", "wgrad"):
                 for kernel in ("pipe", "old"):
                     r = run_case(cin, cout, w, n, what, kernel, a.reps)
                     rows.append(r)
