@@ -499,7 +499,6 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     return DDPM_OK;
 }
 
-int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d);                    // conv_wgrad_pipe.hip
 int ddpm_conv_wgrad_pipe_try(const ddpm_wgrad_desc* d, hipStream_t stream);
 
 extern "C" int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d) {

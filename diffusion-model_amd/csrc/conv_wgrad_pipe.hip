@@ -34,9 +34,9 @@ template <> struct Geo<4> { static constexpr int PW = 6, NPIX = 4 * 36, XSLOTS =
 template <int W> constexpr int stage_bytes() { return Geo<W>::NPIX * PS + CH * DS; }
 
 struct WpArgs {
-    const bf16* x; const bf16* dy;
+    const bf16* x; const bf16* x1; const bf16* dy;      // x1: second source of a concatenated input (channels C0 ..), or null
     float* dw; float* part; long long dw_numel;
-    int Cin, Cout;
+    int Cin, Cout, C0;                                  // Cin = C0 + C1
     int nchunks, splits, tiles;           // 64-position chunks in all; position splits (multiple of 8); channel tiles
     int ncib;                             // input-channel blocks (tile = cob * ncib + cib)
 };
@@ -87,6 +87,10 @@ __global__ __launch_bounds__(WT) void conv_wgrad_pipe_kernel(const WpArgs a) {
         d_goff[u] = row * a.Cout + co0 + vec * 8;
         d_lds[u] = PATCH + row * DS + vec * 16;
     }
+    // the input-channel block lies in one of the two sources of a concatenated input (both are multiples of the block)
+    const bool second = ci0 >= a.C0;
+    const bf16* const xsrc = second ? a.x1 : a.x;
+    const int xcs = second ? a.Cin - a.C0 : a.C0, xc0 = second ? ci0 - a.C0 : ci0;
     int x_goff[G::XSLOTS], x_lds[G::XSLOTS], x_prow[G::XSLOTS];
 #pragma unroll
     for (int u = 0; u < G::XSLOTS; ++u) {
@@ -94,19 +98,19 @@ __global__ __launch_bounds__(WT) void conv_wgrad_pipe_kernel(const WpArgs a) {
         if constexpr (W == 16) {
             const int prow = idx >> 7, px = (idx >> 3) & 15, vec = idx & 7;        // six patch rows (image rows y0 - 1 .. y0 + 4) of 16 pixels
             x_prow[u] = idx < 768 ? prow : -1;
-            x_goff[u] = ((prow - 1) * 16 + px) * a.Cin + ci0 + vec * 8;
+            x_goff[u] = ((prow - 1) * 16 + px) * xcs + xc0 + vec * 8;
             x_lds[u] = (prow * 18 + px + 1) * PS + vec * 16;
         } else {
             const int pos = idx >> 3, vec = idx & 7;
             x_prow[u] = 1;
-            x_goff[u] = pos * a.Cin + ci0 + vec * 8;
+            x_goff[u] = pos * xcs + xc0 + vec * 8;
             x_lds[u] = pix_of<W>(pos) * PS + vec * 16;
         }
     }
     bf16x8 dv[2], xv[G::XSLOTS];
     auto fetch = [&](int c) {
         const bf16* db = a.dy + (long long)c * CH * a.Cout;
-        const bf16* xb = a.x + (long long)c * CH * a.Cin;
+        const bf16* xb = xsrc + (long long)c * CH * xcs;
 #pragma unroll
         for (int u = 0; u < 2; ++u) dv[u] = *(const bf16x8*)(db + d_goff[u]);
 #pragma unroll
@@ -214,14 +218,14 @@ int launch(const WpArgs& a, hipStream_t stream) {
 bool plan(const ddpm_wgrad_desc* d, WpArgs& a) {
     const int mode = ddpm_conv_pipe_mode_now();
     if (mode < 0) return false;
-    if (d->kind != DDPM_CONV_3X3_S1 || d->C1 != 0 || d->in_add || d->in_mask || d->tiles_per_split > 0) return false;    // (grouped launches size their partial rows for the tap-list kernel)
+    if (d->kind != DDPM_CONV_3X3_S1 || d->in_add || d->in_mask || d->tiles_per_split > 0) return false;    // (grouped launches size their partial rows for the tap-list kernel)
     if (d->IH != d->IW || (d->IW != 4 && d->IW != 8 && d->IW != 16)) return false;
-    if (d->C0 % CIB || d->Cout % COB || d->dy_cs != d->Cout) return false;
+    if (d->C0 % CIB || d->C1 % CIB || d->Cout % COB || d->dy_cs != d->Cout) return false;
     const long long rows = (long long)d->N * d->IH * d->IW;
     if (rows % CH || rows / CH > 0x7fffffffll / CH) return false;
-    a.Cin = d->C0; a.Cout = d->Cout;
+    a.Cin = d->C0 + d->C1; a.Cout = d->Cout; a.C0 = d->C0;
     a.nchunks = (int)(rows / CH);
-    a.ncib = d->C0 / CIB;
+    a.ncib = a.Cin / CIB;
     a.tiles = (d->Cout / COB) * a.ncib;
     int splits = (256 / a.tiles) & ~7;                  // one workgroup per CU; a multiple of 8 (one XCD per split)
     if (splits < 8) splits = 8;
@@ -230,14 +234,14 @@ bool plan(const ddpm_wgrad_desc* d, WpArgs& a) {
     while (splits > 8 && a.nchunks < splits) splits -= 8;
     if (a.nchunks < splits) return false;
     a.splits = splits;
-    a.dw_numel = 9ll * d->Cout * d->C0;
+    a.dw_numel = 9ll * d->Cout * a.Cin;
     return true;
 }
 
 }  // namespace
 
 // Number of `part` rows the pipelined kernel writes for this problem, or 0 when it does not take it.
-int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d) {
+extern "C" int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d) {
     WpArgs a;
     return plan(d, a) ? a.splits : 0;
 }
@@ -246,7 +250,7 @@ int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d) {
 int ddpm_conv_wgrad_pipe_try(const ddpm_wgrad_desc* d, hipStream_t stream) {
     WpArgs a;
     if (!plan(d, a)) return 0;
-    a.x = (const bf16*)d->in0; a.dy = (const bf16*)d->dy; a.dw = d->dw; a.part = d->part;
+    a.x = (const bf16*)d->in0; a.x1 = (const bf16*)d->in1; a.dy = (const bf16*)d->dy; a.dw = d->dw; a.part = d->part;
     const int rc = d->IW == 16 ? launch<16>(a, stream) : d->IW == 8 ? launch<8>(a, stream) : launch<4>(a, stream);
     return rc == DDPM_OK ? 1 : -1;
 }

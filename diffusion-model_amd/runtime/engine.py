@@ -316,6 +316,7 @@ class UNetEngine:
         part_ws: List[Optional[Tensor]] = [None]
 
         pending: List = []                            # deferred weight-gradient problems: (descriptor, cost, tensors kept alive)
+        late_wgrad: List[Callable[[], None]] = []     # deferred weight-gradient problems that run as launches of their own
         first_time: List[Tuple[Tensor, int]] = []     # (separately allocated piece, its offset) until the total is known
 
         def part_alloc(numel: int) -> Tuple[Tensor, int]:
@@ -360,6 +361,18 @@ class UNetEngine:
             of a small weight block); the end-of-backward reduction folds the rows into the gradient buffer"""
             gw = G[name + ".weight"]
             tps = self._cur_tps if self.group_wgrad else 0
+            if self.group_wgrad:
+                # deep wide 3x3 problems at large batch leave the group for the pipelined kernel (a launch of their own, with
+                # the group at the end of the phase)
+                ps = ops.conv_wgrad_pipe_splits(kind, x0t, dyt, cout, x1=x1, in_add=in_add, in_mask=in_mask)
+                if ps > 0:
+                    numel = gw.numel()
+                    buf, off = part_alloc(ps * numel)
+                    late_wgrad.append(lambda: ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, part=buf))
+                    dst = G.offset(name + ".weight")
+                    for c0 in range(0, numel, 4096):
+                        part_entries.append((off + c0, dst + c0, ps, numel, min(4096, numel - c0)))
+                    return
             splits = ops.conv_wgrad_splits(kind, x0t, dyt, cout, x1=x1, tiles_per_split=tps)
             if splits <= 1 and not self.group_wgrad:
                 ops.conv_wgrad(kind, x0t, dyt, cout, gw, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale)
@@ -798,6 +811,9 @@ class UNetEngine:
             for ph, fn in late:
                 if ph == phase:
                     fn()
+            for fn in late_wgrad:
+                fn()
+            late_wgrad.clear()
             if pending:
                 self._launch_wgrad_group(pending, dev)
                 pending.clear()

@@ -164,6 +164,7 @@ _PROTOS = {
     "ddpm_remap": ([_vp, _vp, _i, _i, _vp], _i),
     "ddpm_remap_chunk_elems": ([], _i),
     "ddpm_conv_wgrad_splits": ([_vp], _i),
+    "ddpm_conv_wgrad_pipe_splits": ([_vp], _i),
     "ddpm_conv_wgrad_group_bytes": ([_i], _i64),
     "ddpm_conv_wgrad_group_plan": ([_vp, _i, _vp, _i64], _i),
     "ddpm_conv_wgrad_group_launch": ([_vp, _vp, _vp], _i),

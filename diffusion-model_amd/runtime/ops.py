@@ -176,6 +176,15 @@ def conv_wgrad_splits(kind: int, x0: Tensor, dy: Tensor, cout: int, *, x1: Optio
     return r
 
 
+def conv_wgrad_pipe_splits(kind: int, x0: Tensor, dy: Tensor, cout: int, *, x1: Optional[Tensor] = None, in_add=None, in_mask=None) -> int:
+    """Rows of `part` when a standalone conv_wgrad (tiles_per_split = 0) would run on the pipelined kernel for deep wide 3x3
+    convolutions at large batch; 0 when it would not (shape, fused input transforms, or too small to pay)."""
+    if kind != hip.CONV_3X3_S1 or in_add is not None or in_mask is not None:
+        return 0
+    d = wgrad_desc(kind, x0, dy, cout, None, None, x1, None, None, 1.0, 0)
+    return int(hip.lib().ddpm_conv_wgrad_pipe_splits(C.byref(d)))
+
+
 def wgrad_cost(kind, x0, dy, cout, x1=None):
     """() -> (algorithmic bytes, flops, shape tag) of one weight-gradient problem"""
     n, ih, iw, c0 = x0.shape

@@ -331,3 +331,44 @@ def test_config5_four_stage_denoiser_on_64x64x32_latents(dev):
     assert abs(lg - lb16.item()) < 5e-3 * abs(lb16.item()), (lg, lb16.item())
     errs = sorted(l2_err(q.grad.cpu(), gb16[k]) for k, q in m.named_parameters())
     assert errs[len(errs) // 2] < 0.07 and errs[-1] < 0.2, (errs[len(errs) // 2], errs[-1])
+
+
+def test_engine_sends_deep_wide_weight_gradients_to_the_pipelined_kernel(dev):
+    """64x64x3, batch 32: with the pipelined kernels forced, the latent layers' 3x3 weight gradients (256 -> 512 -> 256 at
+    4x4) leave the grouped launch for the pipelined kernel; every gradient of the network must agree with the run that
+    keeps them in the group (same bf16 products, fp32 sums in another order)."""
+    from dm_amd.runtime import hip, ops
+    m, cfg, p = build(dev, 3, "gelu")
+    m.train()
+    m.model.use_graphs = False
+    n = 32
+    x0 = hash_uniform((n, 3, 64, 64), 71) * 2 - 1
+    t = (hash_uniform((n,), 72) * 119).long() + 1
+    noise = hash_normal((n, 3, 64, 64), 73)
+
+    def grads(mode):
+        prev = hip.lib().ddpm_conv_pipe_mode(mode)
+        try:
+            for q in m.parameters():
+                q.grad = None
+            x_t = m.q(x0.to(dev), t.to(dev), noise=noise.to(dev))
+            pred = m(x_t, t.to(dev))
+            loss = ELBOLoss("mse")(m, t.to(dev), pred, x0.to(dev))["Loss"]
+            loss.backward()
+            return loss.item(), {k: q.grad.detach().float().cpu().clone() for k, q in m.named_parameters()}
+        finally:
+            hip.lib().ddpm_conv_pipe_mode(prev)
+
+    la, ga = grads(-1)
+    prev = hip.lib().ddpm_conv_pipe_mode(1)
+    try:
+        xa = torch.zeros(n, 4, 4, 256, device=dev, dtype=torch.bfloat16)
+        dya = torch.zeros(n, 4, 4, 512, device=dev, dtype=torch.bfloat16)
+        assert ops.conv_wgrad_pipe_splits(hip.CONV_3X3_S1, xa, dya, 512) > 0
+    finally:
+        hip.lib().ddpm_conv_pipe_mode(prev)
+    lb, gb = grads(1)
+    assert abs(la - lb) <= 2e-2 * abs(la)            # (the forward pass takes the pipelined convolution kernel as well)
+    worst = max((l2_err(gb[k], ga[k]), k) for k in ga)
+    print("largest per-tensor difference between the two kernel choices:", worst)
+    assert worst[0] < 5e-2, worst

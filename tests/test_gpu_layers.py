@@ -188,6 +188,24 @@ def test_conv_wgrad_pipelined_kernel(dev, n, ci, co, w_):
     assert_rel(dwk.cpu(), old.cpu(), 1e-4)                           # same bf16 products, fp32 sums in another order
 
 
+def test_conv_wgrad_pipelined_kernel_two_sources(dev):
+    """concatenated input (two NHWC sources): an input-channel block of the pipelined kernel reads from one of them"""
+    n, c0, c1, co, h = 24, 64, 128, 128, 8
+    x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))
+    w = torch.zeros(co, c0 + c1, 3, 3, requires_grad=True)
+    ref = F.conv2d(torch.cat([x0, x1], 1), w, None, padding=1)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    (gw,) = torch.autograd.grad(ref, w, gy)
+    dwk = torch.zeros(9, co, c0 + c1, device=dev)
+    prev = hip.lib().ddpm_conv_pipe_mode(1)
+    try:
+        assert ops.conv_wgrad_pipe_splits(hip.CONV_3X3_S1, nhwc(x0, dev), nhwc(gy, dev), co, x1=nhwc(x1, dev)) > 0
+        ops.conv_wgrad(hip.CONV_3X3_S1, nhwc(x0, dev), nhwc(gy, dev), co, dwk, x1=nhwc(x1, dev))
+    finally:
+        hip.lib().ddpm_conv_pipe_mode(prev)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, dwk.cpu(), co, c0 + c1), gw, 5e-3)
+
+
 def test_conv_wgrad_fused_input(dev):
     n, c0, c1, co, h = 3, 64, 64, 64, 8
     x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_cs && mkdir -p /tmp/prof_cs
 i=0
-DEFAULT="128,128,16,4096,fwd,pipe 128,128,16,4096,dgrad,pipe 256,256,8,16384,fwd,pipe 256,256,8,16384,dgrad,pipe 256,512,4,65536,fwd,pipe 512,256,4,65536,fwd,pipe 512,256,4,65536,dgrad,pipe 128,128,16,4096,fwd,old 256,256,8,16384,fwd,old 512,256,4,65536,fwd,old 128,128,16,4096,wgrad,old 256,256,8,16384,wgrad,old 512,256,4,65536,wgrad,old"
+DEFAULT="128,128,16,4096,fwd,pipe 128,128,16,4096,dgrad,pipe 256,256,8,16384,fwd,pipe 256,256,8,16384,dgrad,pipe 256,512,4,65536,fwd,pipe 512,256,4,65536,fwd,pipe 512,256,4,65536,dgrad,pipe 128,128,16,4096,fwd,old 256,256,8,16384,fwd,old 512,256,4,65536,fwd,old 128,128,16,4096,wgrad,old 256,256,8,16384,wgrad,old 512,256,4,65536,wgrad,old 128,128,16,4096,wgrad,pipe 256,256,8,16384,wgrad,pipe 256,512,4,65536,wgrad,pipe 512,256,4,65536,wgrad,pipe"
 CASES=${CASES:-$DEFAULT}
 for case in $CASES; do
   i=$((i+1))
