@@ -186,11 +186,12 @@ def act_entries(site: str, activation: str) -> list:
     return [(site + ".beta", (), ONES)] if has_scalar(activation) else []
 
 
-def sir_entries(pre: str, c: int, expand, activation: str = "gelu") -> list:
+def sir_entries(pre: str, c: int, expand, activation: str = "gelu", out_channels: int = 0) -> list:
     e = int(expand * c)
+    co = out_channels or c
     return (conv_entries(pre + "expansion.1", e, c, 1) + norm_entries(pre + "expansion.2", e) + act_entries(pre + "expansion.3", activation) +
             conv_entries(pre + "depthwise.1", e, 1, 3) + norm_entries(pre + "depthwise.2", e) + act_entries(pre + "depthwise.3", activation) +
-            conv_entries(pre + "projection.1", c, e, 1) + norm_entries(pre + "projection.2", c))
+            conv_entries(pre + "projection.1", co, e, 1) + norm_entries(pre + "projection.2", co))
 
 
 def check_activation(name: str) -> None:

@@ -14,24 +14,27 @@ class SeparableInvertResidual(BlockModule):
                  base_groups_norm: int = 4, activation: str = "swish", initializer="he_uniform", device=None, dtype=None, *args, **kwargs):
         super().__init__()
         check_activation(activation)
-        if in_channels != out_channels or stride != 1:
-            raise ValueError("only the residual form (in_channels == out_channels, stride 1) is built: it is the only one the "
-                             "reference's UNet instantiates (constituent_blocks.py:77-80,186-192)")
-        if in_channels % 32:
-            raise ValueError(f"channel counts must be multiples of 32 for the MFMA kernels, got {in_channels}")
-        self.is_residual = True
-        self.in_channels, self.expand_factor = in_channels, expand_factor
+        if stride not in (1, 2):
+            raise ValueError(f"the depthwise convolution's stride is 1 or 2, got {stride}")
+        if in_channels % 32 or out_channels % 32:
+            raise ValueError(f"channel counts must be multiples of 32 for the MFMA kernels, got {in_channels} -> {out_channels}")
+        # conv_block.py:51-54 of the reference: the block adds its input only when it keeps the shape.  The residual form is the
+        # one the reference's UNet builds (constituent_blocks.py:77-80,186-192) and the one with a single-launch kernel; the
+        # others run on the per-unit kernels.
+        self.is_residual = in_channels == out_channels and stride == 1
+        self.in_channels, self.out_channels, self.stride, self.expand_factor = in_channels, out_channels, int(stride), expand_factor
         spec = BlockSpec({"expansion.1": hip.CONV_1X1, "projection.1": hip.CONV_1X1}, ["depthwise.1"], expand_factor, drop_p, activation,
                          base_groups_norm)
-        self._build(sir_entries("", in_channels, expand_factor, activation), spec, initializer, device, dtype)
+        self._build(sir_entries("", in_channels, expand_factor, activation, out_channels), spec, initializer, device, dtype)
 
     def _program(self, units, inputs):
-        return units.sir("", inputs[0])
+        return units.sir("", inputs[0], residual=self.is_residual, stride=self.stride)
 
     def _site_sizes(self, shapes):
         n, h, w, c = shapes[0]
         e = int(self.expand_factor * c)
-        return [n * h * w * c, n * h * w * e, n * h * w * e]
+        ho, wo = (h + self.stride - 1) // self.stride, (w + self.stride - 1) // self.stride
+        return [n * h * w * c, n * h * w * e, n * ho * wo * e]
 
     def forward(self, input):
         return self._run(input)

@@ -584,20 +584,26 @@ class UNetEngine:
                 tape.append(bwd)
             return out
 
-        def dw_unit(pre: str, xin: Var, out_mask) -> Var:
-            """depthwise 3x3 -> GroupNorm -> act [-> * out_mask]   (conv_block.py:77-96)"""
+        def dw_unit(pre: str, xin: Var, out_mask, stride: int = 1) -> Var:
+            """depthwise 3x3 -> GroupNorm -> act [-> * out_mask]   (conv_block.py:77-96).  stride 2 (conv_block.py:84; a form
+            the reference's UNet never builds): with padding 1 the strided result is every second pixel of the stride-1
+            result, so the stride-1 kernel runs and a strided copy thins it out (4x the arithmetic of a dedicated kernel, on
+            a path nothing hot takes)."""
             name, norm = pre + "depthwise.1", pre + "depthwise.2"
-            raw, spart = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"], gn_part_groups=sp.groups) if self.conv_stats else (
-                ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"]), None)
+            if stride == 2:
+                raw, spart = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"])[:, ::2, ::2, :].contiguous(), None
+            else:
+                raw, spart = ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"], gn_part_groups=sp.groups) if self.conv_stats else (
+                    ops.dwconv3x3(xin.v, wc.dw[name], P[name + ".bias"]), None)
             gamma, beta = P[norm + ".weight"], P[norm + ".bias"]
             y, stats = ops.gn_act_forward(raw, gamma, beta, sp.groups, sp.act, mask=out_mask, mask_scale=mscale,
                                           act_beta=act_scalar(act_site(norm), sp.act), stat_part=spart)
             out = Var(y)
             if tape is not None:
-                tape.append(dw_bwd(pre, xin, raw, out, stats, out_mask))
+                tape.append(dw_bwd(pre, xin, raw, out, stats, out_mask, stride))
             return out
 
-        def dw_bwd(pre, xin, raw, out, stats, out_mask):
+        def dw_bwd(pre, xin, raw, out, stats, out_mask, stride: int = 1):
             name, norm = pre + "depthwise.1", pre + "depthwise.2"
             gamma, beta = P[norm + ".weight"], P[norm + ".bias"]
 
@@ -608,6 +614,10 @@ class UNetEngine:
                                            mask=out_mask, mask_scale=mscale, act_beta=bsc,
                                            dbeta_part=None if bsc is None else scalar_partials(act_site(norm), n * cch))
                 out.g = None
+                if stride == 2:          # the adjoint of the thinning copy: the gradient on every second pixel, zeros between
+                    wide = torch.zeros(xin.v.shape, device=draw.device, dtype=draw.dtype)
+                    wide[:, ::2, ::2, :] = draw
+                    draw = wide
                 nb = ops.dwconv3x3_wgrad_blocks(*xin.v.shape)
                 buf, off = part_alloc(nb * 10 * cch)
                 ops.dwconv3x3_wgrad(xin.v, draw, buf)
@@ -617,14 +627,19 @@ class UNetEngine:
                 xin.g = ops.dwconv3x3(draw, wc.dw_flip[name], None)
             return bwd
 
-        def sir(pre: str, xin: Var) -> Var:
+        def sir(pre: str, xin: Var, residual: bool = True, stride: int = 1) -> Var:
             """SeparableInvertResidual (conv_block.py:132-136).  The three nn.Dropout sites act on the block input
             (fused into the expansion conv's loader) and on the two intermediate activations (fused into the
-            GroupNorm epilogue that produces them)."""
+            GroupNorm epilogue that produces them).  residual = False / stride = 2: the forms that change the shape and add
+            no input (conv_block.py:51-54,84), on the per-unit kernels."""
             m_in, m_e, m_d = next_mask(), next_mask(), next_mask()
             _, hh, ww, cc = xin.v.shape
             ne, nd, npj = pre + "expansion.1", pre + "depthwise.1", pre + "projection.1"
             ech = P[nd + ".bias"].shape[0]
+            if not residual or stride != 1:
+                e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
+                d = dw_unit(pre, e, m_d, stride)
+                return conv_unit(pre + "projection.1", d, norm=pre + "projection.2", groups=sp.groups, act=0)
             if self.fuse_sir and ops.sir_supported(cc, hh, ww, ech, sp.groups, sp.act):
                 # whole block in one launch (activations resident in LDS); training saves what the per-unit backward needs
                 g1, g2, g3 = pre + "expansion.2", pre + "depthwise.2", pre + "projection.2"

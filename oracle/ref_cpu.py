@@ -200,17 +200,19 @@ def conv_gn_act(p: Params, conv: str, gn: str, x: Tensor, groups: int, act, *, s
     return _r(act(y, gn[:-2] + "2"))          # Sequential(conv, GroupNorm, activation): the activation is module 2
 
 
-def sir_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks) -> Tensor:
+def sir_block(p: Params, pre: str, x: Tensor, groups: int, act, drop: DropMasks, stride: int = 1) -> Tensor:
     """SeparableInvertResidual.forward (conv_block.py:57-136): three conv+GN stages, each fed a
-    dropped-out input; the residual adds the un-dropped block input."""
+    dropped-out input; the residual adds the un-dropped block input when the block keeps the shape
+    (in_channels == out_channels and stride 1, conv_block.py:51-54); `stride` is the depthwise
+    convolution's (conv_block.py:84)."""
     e = _r(F.conv2d(_r(drop(x)), _r(p[pre + "expansion.1.weight"]), p[pre + "expansion.1.bias"]))
     e = _r(drop(act(F.group_norm(e, groups, p[pre + "expansion.2.weight"], p[pre + "expansion.2.bias"], eps=1e-5), pre + "expansion.3")))
     c = e.shape[1]
-    d = _r(F.conv2d(e, p[pre + "depthwise.1.weight"], p[pre + "depthwise.1.bias"], padding=1, groups=c))
+    d = _r(F.conv2d(e, p[pre + "depthwise.1.weight"], p[pre + "depthwise.1.bias"], stride=stride, padding=1, groups=c))
     d = _r(drop(act(F.group_norm(d, groups, p[pre + "depthwise.2.weight"], p[pre + "depthwise.2.bias"], eps=1e-5), pre + "depthwise.3")))
     o = _r(F.conv2d(d, _r(p[pre + "projection.1.weight"]), p[pre + "projection.1.bias"]))
     o = F.group_norm(o, groups, p[pre + "projection.2.weight"], p[pre + "projection.2.bias"], eps=1e-5)
-    if o.shape == x.shape:
+    if o.shape == x.shape and stride == 1:
         o = o + x
     return _r(o)
 

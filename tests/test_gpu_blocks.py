@@ -41,6 +41,16 @@ def test_separable_invert_residual(golden, dev, act):
     check(SeparableInvertResidual(32, 32, activation=act, **KW), golden("blocks.pt")[f"sir.{act}"], ["x"], ["gx"], dev, 0.1, 0.99)
 
 
+@pytest.mark.parametrize("tag", ["c32to64.s1", "c32to64.s2", "c64.s2"])
+def test_separable_invert_residual_without_residual_and_with_stride(golden, dev, tag):
+    """the forms of the block the reference's UNet never builds (conv_block.py:51-54,84-86 there): another output width,
+    stride 2 in the depthwise convolution; fixtures from the reference class"""
+    fx = golden("sir_variants.pt")[tag]
+    blk = SeparableInvertResidual(fx["in_channels"], fx["out_channels"], stride=fx["stride"], activation="gelu", **KW)
+    assert not blk.is_residual
+    check(blk, fx, ["x"], ["gx"], dev, 0.1, 0.99)
+
+
 @pytest.mark.parametrize("act", ["gelu", "silu"])
 def test_down_block(golden, dev, act):
     check(DownBlock(in_channels=32, out_channels=64, is_conditional=False, activation=act, **KW), golden("blocks.pt")[f"down.{act}"],
@@ -80,7 +90,9 @@ def test_train_mode_dropout_and_module_plumbing(dev):
     m2 = copy.deepcopy(m)
     assert torch.equal(m2(x), m(x)) and len(m.state_dict()) == 12
     with pytest.raises(ValueError):
-        SeparableInvertResidual(32, 64, expand_factor=2, activation="gelu")
+        SeparableInvertResidual(32, 48, expand_factor=2, activation="gelu")          # widths are multiples of 32
+    with pytest.raises(ValueError):
+        SeparableInvertResidual(32, 32, expand_factor=2, stride=3, activation="gelu")
 
 
 # ---- ConditionalModule (constituent_blocks.py:331-437 of the reference): fixtures from the reference class itself, for

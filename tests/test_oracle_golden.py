@@ -66,6 +66,22 @@ def test_blocks(golden, act):
     close(O.embed_block(e["params"], "", sin, a), e["y"])
 
 
+def test_inverted_residual_without_residual_and_with_stride(golden):
+    """the block forms the reference's UNet never builds: other output width, stride 2 (conv_block.py:51-54,84-86)"""
+    g = golden("sir_variants.pt")
+    a = O.act_fn("gelu")
+    for tag in ("c32to64.s1", "c32to64.s2", "c64.s2"):
+        rec = g[tag]
+        leaves = {k: v.clone().requires_grad_(True) for k, v in rec["params"].items()}
+        x = rec["x"].clone().requires_grad_(True)
+        y = O.sir_block(leaves, "", x, 16, a, O.DropMasks(), stride=rec["stride"])
+        close(y, rec["y"], 1e-4, 1e-5)
+        grads = torch.autograd.grad(y, [x] + list(leaves.values()), rec["gy"])
+        close(grads[0], rec["gx"], 1e-4, 1e-4)
+        for k, gp in zip(leaves, grads[1:]):
+            close(gp, rec["gparams"][k], 1e-4, 2e-4)
+
+
 def _digest_close(g, d, rtol):
     flat = g.reshape(-1).double()
     l2 = flat.norm().item()

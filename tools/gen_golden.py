@@ -210,6 +210,25 @@ def gen_blocks():
     save("blocks.pt", out)
 
 
+def gen_sir_variants():
+    """The forms of SeparableInvertResidual the reference's UNet never builds (conv_block.py:51-54,84-86): other output width,
+    stride 2 in the depthwise convolution; no residual add in either."""
+    out = {}
+    kw = dict(expand_factor=2, drop_p=0.0, base_groups_norm=4, activation="gelu", initializer="he_normal")
+    for tag, cin, cout, stride in (("c32to64.s1", 32, 64, 1), ("c32to64.s2", 32, 64, 2), ("c64.s2", 64, 64, 2)):
+        blk = SeparableInvertResidual(cin, cout, stride=stride, **kw).eval()
+        assert not blk.is_residual
+        sd = {k: O.hash_fill(v.shape, 307 + i, 0.25, 1.0 if (k.endswith("2.weight")) else 0.0) for i, (k, v) in enumerate(blk.state_dict().items())}
+        blk.load_state_dict(sd)
+        x = hash_normal((3, cin, 8, 8), 331).requires_grad_(True)
+        y = blk(x)
+        gy = hash_normal(tuple(y.shape), 332)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        out[tag] = {"params": sd, "x": x.detach(), "y": y.detach(), "gy": gy, "gx": grads[0], "gparams": dict(zip(sd.keys(), grads[1:])),
+                    "in_channels": cin, "out_channels": cout, "stride": stride}
+    save("sir_variants.pt", out)
+
+
 def gen_unet_full():
     out = {}
     for tag, c, act in (("c3.gelu", 3, "gelu"), ("c1.gelu", 1, "gelu"), ("c3.silu", 3, "silu")):
@@ -435,6 +454,6 @@ def gen_autoencoder():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_schedule_and_ops, gen_blocks, gen_unet_full, gen_sample_chain, gen_conditional, gen_beta_activations, gen_autoencoder):
+    for fn in (gen_schedule_and_ops, gen_blocks, gen_sir_variants, gen_unet_full, gen_sample_chain, gen_conditional, gen_beta_activations, gen_autoencoder):
         if not only or fn.__name__ in only:
             fn()
