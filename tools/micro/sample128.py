@@ -14,7 +14,7 @@ dev = torch.device("cuda", 0)
 m = build_model(dev, 3, [2])
 m.eval()
 for nb in [int(v) for v in sys.argv[1:]] or [128, 256, 512]:
-    smp = graphs.GraphedSampler(m, nb, (128, 128))
+    smp = graphs.GraphedSampler(m, nb, (128, 128), use_graph=os.environ.get("NOGRAPH") != "1")     # NOGRAPH=1: plain launches (counter passes)
     smp.begin()
     for _ in range(3):
         smp.step()

@@ -24,11 +24,17 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 python3 $R/tools/profile_summary.py stats /tmp/prof/stats64 $OUT/kernel_stats_64x64x3.csv
 timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof/mfma64 -o r -- python3 $R/bench.py --steps 3 --warmup 2 --no-graph $B64 > /tmp/prof/mfma64.out 2> /tmp/prof/mfma64.err
 python3 $R/tools/profile_summary.py mfma /tmp/prof/mfma64 /tmp/prof/stats64 $OUT/mfma_util_64x64x3.json
-# the attention kernels: a training step at 128x128x3 with self-attention at the 16x16 stage (stage 3), kernel statistics and
+# the attention kernels: a training step at 128x128x3 with self-attention at the 16x16 stage (stage 2), kernel statistics and
 # the matrix-core counters in passes of their own
-BAT="--size 128 --channels 3 --batch 16 --attention-stages 3 --no-sample --no-cpu --no-roofline --no-extra"
+BAT="--size 128 --channels 3 --batch 16 --attention-stages 2 --no-sample --no-cpu --no-roofline --no-extra"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/statsat -o r -- python3 $R/bench.py --steps 10 --warmup 3 $BAT > /tmp/prof/statsat.out 2> /tmp/prof/statsat.err
 python3 $R/tools/profile_summary.py stats /tmp/prof/statsat $OUT/kernel_stats_128x128x3_attention.csv
 timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof/mfmaat -o r -- python3 $R/bench.py --steps 3 --warmup 2 --no-graph $BAT > /tmp/prof/mfmaat.out 2> /tmp/prof/mfmaat.err
 python3 $R/tools/profile_summary.py mfma /tmp/prof/mfmaat /tmp/prof/statsat $OUT/mfma_util_128x128x3_attention.json
+# the attention forward at a saturating batch: sampling steps of 256 images (2048 head problems of 256 tokens), plain launches
+export NOGRAPH=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/statsas -o r -- python3 $R/tools/micro/sample128.py 256 > /tmp/prof/statsas.out 2> /tmp/prof/statsas.err
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof/mfmaas -o r -- python3 $R/tools/micro/sample128.py 256 > /tmp/prof/mfmaas.out 2> /tmp/prof/mfmaas.err
+unset NOGRAPH
+python3 $R/tools/profile_summary.py mfma /tmp/prof/mfmaas /tmp/prof/statsas $OUT/mfma_util_sample128_attention.json
 ls -la $OUT
