@@ -35,6 +35,7 @@ template <int W> constexpr int stage_bytes() { return Geo<W>::NPIX * PS + CH * D
 
 struct WpArgs {
     const bf16* x; const bf16* x1; const bf16* dy;      // x1: second source of a concatenated input (channels C0 ..), or null
+    const float* in_add; const unsigned char* in_mask; float in_mask_scale;      // the forward loader's transforms of source 0
     float* dw; float* part; long long dw_numel;
     int Cin, Cout, C0;                                  // Cin = C0 + C1
     int nchunks, splits, tiles;           // 64-position chunks in all; position splits (multiple of 8); channel tiles
@@ -58,7 +59,7 @@ template <int W> __device__ __forceinline__ constexpr int pix_of(int k) {
     else return (k >> 4) * 36 + (((k >> 2) & 3) + 1) * 6 + (k & 3) + 1;
 }
 
-template <int W>
+template <int W, bool XF>
 __global__ __launch_bounds__(WT) void conv_wgrad_pipe_kernel(const WpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<W>;
@@ -107,10 +108,19 @@ __global__ __launch_bounds__(WT) void conv_wgrad_pipe_kernel(const WpArgs a) {
             x_lds[u] = pix_of<W>(pos) * PS + vec * 16;
         }
     }
+    // the forward pass's loader transforms of source 0 (time-embedding add, then dropout mask: conv_mfma.hip), applied to the
+    // fetched vector exactly as there: each rounds to bf16
+    const bool xform = XF && !second;
+    int x_img[G::XSLOTS];                               // image of the slot's pixel, relative to the chunk's first image
+#pragma unroll
+    for (int u = 0; u < G::XSLOTS; ++u) x_img[u] = W == 4 ? ((tid + u * WT) >> 3) >> 4 : 0;
     bf16x8 dv[2], xv[G::XSLOTS];
+    f32x4 xa[G::XSLOTS][2];
+    unsigned xm[G::XSLOTS];
     auto fetch = [&](int c) {
         const bf16* db = a.dy + (long long)c * CH * a.Cout;
         const bf16* xb = xsrc + (long long)c * CH * xcs;
+        const long long img0 = W == 16 ? c >> 2 : W == 8 ? c : 4ll * c;
 #pragma unroll
         for (int u = 0; u < 2; ++u) dv[u] = *(const bf16x8*)(db + d_goff[u]);
 #pragma unroll
@@ -123,14 +133,39 @@ __global__ __launch_bounds__(WT) void conv_wgrad_pipe_kernel(const WpArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[u][j] = (bf16)0.f;
             if (ok) xv[u] = *(const bf16x8*)(xb + x_goff[u]);
+            if constexpr (XF) {
+                xm[u] = 0xFFu;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xa[u][0][j] = 0.f; xa[u][1][j] = 0.f; }
+                if (xform && ok) {
+                    if (a.in_add) {
+                        const float* ap = a.in_add + (img0 + x_img[u]) * a.C0 + xc0 + ((tid + u * WT) & 7) * 8;
+                        xa[u][0] = *(const f32x4*)ap; xa[u][1] = *(const f32x4*)(ap + 4);
+                    }
+                    if (a.in_mask) xm[u] = a.in_mask[((long long)c * CH * xcs + x_goff[u]) >> 3];
+                }
+            }
         }
     };
     auto stash = [&](char* st) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) *(bf16x8*)(st + d_lds[u]) = dv[u];
 #pragma unroll
-        for (int u = 0; u < G::XSLOTS; ++u)
+        for (int u = 0; u < G::XSLOTS; ++u) {
+            if constexpr (XF) {
+                if (xform) {          // (vectors of pixels outside the image were fetched as zeros with a zero add and a full mask: they stay zero)
+                    if (a.in_add) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { xv[u][j] = (bf16)((float)xv[u][j] + xa[u][0][j]); xv[u][4 + j] = (bf16)((float)xv[u][4 + j] + xa[u][1][j]); }
+                    }
+                    if (a.in_mask) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[u][j] = (xm[u] >> j) & 1 ? (bf16)((float)xv[u][j] * a.in_mask_scale) : (bf16)0.f;
+                    }
+                }
+            }
             if (x_prow[u] >= 0) *(bf16x8*)(st + x_lds[u]) = xv[u];
+        }
     };
 
     // ---- lane-constant parts of the transposing reads
@@ -197,11 +232,11 @@ __global__ __launch_bounds__(WT) void conv_wgrad_pipe_kernel(const WpArgs a) {
     }
 }
 
-template <int W>
-int launch(const WpArgs& a, hipStream_t stream) {
+template <int W, bool XF>
+int launch_as(const WpArgs& a, hipStream_t stream) {
     constexpr int lds = 2 * stage_bytes<W>();
     static_assert(lds <= 160 * 1024, "stages do not fit LDS");
-    auto k = conv_wgrad_pipe_kernel<W>;
+    auto k = conv_wgrad_pipe_kernel<W, XF>;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -214,11 +249,16 @@ int launch(const WpArgs& a, hipStream_t stream) {
     return ddpm_check_launch("conv_wgrad_pipe");
 }
 
+template <int W>
+int launch(const WpArgs& a, hipStream_t stream) {
+    return (a.in_add || a.in_mask) ? launch_as<W, true>(a, stream) : launch_as<W, false>(a, stream);
+}
+
 // shape part of the decision (the descriptor's pointers are not looked at): fills the split / tile counts
 bool plan(const ddpm_wgrad_desc* d, WpArgs& a) {
     const int mode = ddpm_conv_pipe_mode_now();
     if (mode < 0) return false;
-    if (d->kind != DDPM_CONV_3X3_S1 || d->in_add || d->in_mask || d->tiles_per_split > 0) return false;    // (grouped launches size their partial rows for the tap-list kernel)
+    if (d->kind != DDPM_CONV_3X3_S1 || d->tiles_per_split > 0) return false;    // (grouped launches size their partial rows for the tap-list kernel)
     if (d->IH != d->IW || (d->IW != 4 && d->IW != 8 && d->IW != 16)) return false;
     if (d->C0 % CIB || d->C1 % CIB || d->Cout % COB || d->dy_cs != d->Cout) return false;
     const long long rows = (long long)d->N * d->IH * d->IW;
@@ -251,6 +291,7 @@ int ddpm_conv_wgrad_pipe_try(const ddpm_wgrad_desc* d, hipStream_t stream) {
     WpArgs a;
     if (!plan(d, a)) return 0;
     a.x = (const bf16*)d->in0; a.x1 = (const bf16*)d->in1; a.dy = (const bf16*)d->dy; a.dw = d->dw; a.part = d->part;
+    a.in_add = d->in_add; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
     const int rc = d->IW == 16 ? launch<16>(a, stream) : d->IW == 8 ? launch<8>(a, stream) : launch<4>(a, stream);
     return rc == DDPM_OK ? 1 : -1;
 }

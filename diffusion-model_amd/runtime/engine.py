@@ -368,7 +368,8 @@ class UNetEngine:
                 if ps > 0:
                     numel = gw.numel()
                     buf, off = part_alloc(ps * numel)
-                    late_wgrad.append(lambda: ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, part=buf))
+                    late_wgrad.append(lambda: ops.conv_wgrad(kind, x0t, dyt, cout, None, x1=x1, in_add=in_add, in_mask=in_mask, in_scale=mscale,
+                                                             part=buf))
                     dst = G.offset(name + ".weight")
                     for c0 in range(0, numel, 4096):
                         part_entries.append((off + c0, dst + c0, ps, numel, min(4096, numel - c0)))

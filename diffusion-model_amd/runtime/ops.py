@@ -178,10 +178,10 @@ def conv_wgrad_splits(kind: int, x0: Tensor, dy: Tensor, cout: int, *, x1: Optio
 
 def conv_wgrad_pipe_splits(kind: int, x0: Tensor, dy: Tensor, cout: int, *, x1: Optional[Tensor] = None, in_add=None, in_mask=None) -> int:
     """Rows of `part` when a standalone conv_wgrad (tiles_per_split = 0) would run on the pipelined kernel for deep wide 3x3
-    convolutions at large batch; 0 when it would not (shape, fused input transforms, or too small to pay)."""
-    if kind != hip.CONV_3X3_S1 or in_add is not None or in_mask is not None:
+    convolutions at large batch; 0 when it would not (shape, or too small to pay)."""
+    if kind != hip.CONV_3X3_S1:
         return 0
-    d = wgrad_desc(kind, x0, dy, cout, None, None, x1, None, None, 1.0, 0)
+    d = wgrad_desc(kind, x0, dy, cout, None, None, x1, in_add, in_mask, 1.0, 0)
     return int(hip.lib().ddpm_conv_wgrad_pipe_splits(C.byref(d)))
 
 

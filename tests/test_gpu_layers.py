@@ -206,6 +206,29 @@ def test_conv_wgrad_pipelined_kernel_two_sources(dev):
     assert_rel(unpack_dw(hip.CONV_3X3_S1, dwk.cpu(), co, c0 + c1), gw, 5e-3)
 
 
+@pytest.mark.parametrize("n,h", [(24, 8), (64, 4), (10, 16)])
+def test_conv_wgrad_pipelined_kernel_fused_input(dev, n, h):
+    """the forward loader's transforms of the first source (time-embedding add, then dropout mask) inside the pipelined kernel"""
+    c0, c1, co = 64, 64, 128
+    x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))
+    temb = hash_normal((n, c0), 3)
+    keep = hash_uniform((n, h, h, c0), 6) < 0.9
+    xin = torch.cat([r16(r16(x0 + temb[:, :, None, None]) * keep.permute(0, 3, 1, 2) / 0.9), x1], 1)
+    w = torch.zeros(co, c0 + c1, 3, 3, requires_grad=True)
+    ref = F.conv2d(xin, w, None, padding=1)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    (gw,) = torch.autograd.grad(ref, w, gy)
+    dwk = torch.zeros(9, co, c0 + c1, device=dev)
+    prev = hip.lib().ddpm_conv_pipe_mode(1)
+    try:
+        assert ops.conv_wgrad_pipe_splits(hip.CONV_3X3_S1, nhwc(x0, dev), nhwc(gy, dev), co, x1=nhwc(x1, dev), in_add=temb.to(dev)) > 0
+        ops.conv_wgrad(hip.CONV_3X3_S1, nhwc(x0, dev), nhwc(gy, dev), co, dwk, x1=nhwc(x1, dev), in_add=temb.to(dev),
+                       in_mask=bits(keep).to(dev), in_scale=1 / 0.9)
+    finally:
+        hip.lib().ddpm_conv_pipe_mode(prev)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, dwk.cpu(), co, c0 + c1), gw, 5e-3)
+
+
 def test_conv_wgrad_fused_input(dev):
     n, c0, c1, co, h = 3, 64, 64, 64, 8
     x0, x1 = r16(hash_normal((n, c0, h, h), 1)), r16(hash_normal((n, c1, h, h), 2))
