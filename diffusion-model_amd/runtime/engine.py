@@ -95,9 +95,13 @@ class UNetSpec:
         self.groups = 4 * int(base_groups_norm)
         self.latent_groups = 8 * int(base_groups_norm)
         self.time_norm = float(time_norm)
-        for c in self.stages + [self.latent_dim]:
+        for c, g in [(c, self.groups) for c in self.stages] + [(self.latent_dim, self.latent_groups)]:
             if c % 32:
                 raise ValueError(f"stage/latent channel counts must be multiples of 32 for the MFMA kernels, got {c}")
+            cpg = c // g if g and c % g == 0 else 0
+            if not (cpg in (1, 2, 4) or (cpg % 8 == 0 and 8 <= cpg <= 64)):
+                raise ValueError(f"{c} channels in {g} normalisation groups: the GroupNorm kernels take 1, 2, 4 or a multiple of 8 (up to 64) "
+                                 f"channels per group")
         if self.t_dim % 32:
             raise ValueError(f"t_embed_dim must be a multiple of 32, got {self.t_dim}")
         # stages whose Down/Up blocks carry a self-attention ConditionalModule at layers[1] (where the reference's

@@ -372,3 +372,27 @@ def test_engine_sends_deep_wide_weight_gradients_to_the_pipelined_kernel(dev):
     worst = max((l2_err(gb[k], ga[k]), k) for k in ga)
     print("largest per-tensor difference between the two kernel choices:", worst)
     assert worst[0] < 5e-2, worst
+
+
+def test_24_channel_images_forward_and_gradients_vs_oracle(dev):
+    """A denoiser on 24-channel inputs (the latent width the reference's flowers102 backbone_config hints at, a multiple of 8
+    but not of 16): the image ends pad to 32 channels internally.  Loss within 1e-3, every gradient within the common bound."""
+    kw = dict(YAML, stages_channels=[32, 64], drop_p=0.0)
+    m = dm_ddpm.DDPM(dm_unets.BaseUNet, **kw, is_conditional=False, img_channels=24, reconstruction_method="mse", latent_dim=128, device=dev)
+    cfg = O.UNetCfg(img_channels=24, stages_channels=(32, 64), latent_dim=128, activation="gelu", drop_p=0.0)
+    p = O.hash_params(cfg, seed=1)
+    m.load_state_dict(p)
+    m = m.to(dev).eval()
+    n = 3
+    x0 = hash_uniform((n, 24, 16, 16), 61) * 2 - 1
+    t = torch.tensor([2, 30, 119])
+    noise = hash_normal((n, 24, 16, 16), 62)
+    s = O.make_schedule(120, 0.25)
+    x_t = m.q(x0.to(dev), t.to(dev), noise=noise.to(dev))
+    pred = m(x_t, t.to(dev))
+    loss = ELBOLoss("mse")(m, t.to(dev), pred, x0.to(dev))["Loss"]
+    loss.backward()
+    l32, g32 = O.train_step_grads(p, cfg, s, x0, t, noise)
+    assert abs(loss.item() - float(l32)) < 1e-3 * abs(float(l32)) + 1e-6
+    for k, q in m.named_parameters():
+        assert l2_err(q.grad.cpu(), g32[k]) < (0.35 if "t_embeddings" in k else 0.2), (k, l2_err(q.grad.cpu(), g32[k]))
