@@ -4,6 +4,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence, Tuple, Type, Union
 
+import os
+
 import torch
 from torch import Tensor, nn
 from torch.nn.modules.utils import _pair
@@ -96,6 +98,10 @@ class DDPM(nn.Module):
         safe = torch.empty_like(t)
         hip.call("ddpm_check_timesteps", hip.ptr(t), hip.ptr(safe), t.numel(), lo, self.T, self._t_flag.data_ptr(), hip.stream())
         self._t_what = f"DDPM.{what}: timesteps must lie in [{lo}, {self.T}]"
+        if getattr(self, "strict_timesteps", False) or os.environ.get("DDPM_STRICT_TIMESTEPS") == "1":
+            # the reference's behaviour to the letter: the offending call itself raises (ddpm.py:102-105,138-141 there), at the
+            # price of one host/device rendezvous per call
+            self.check_timesteps(wait=True)
         return safe
 
     def check_timesteps(self, wait: bool = False) -> None:

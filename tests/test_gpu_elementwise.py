@@ -201,6 +201,13 @@ def test_timestep_range_check_does_not_stall_and_raises(dev):
     m.reverse_q(x, x, torch.tensor([0, 3, 4], device=dev), noise=noise)     # the reverse step starts at t = 1
     with pytest.raises(IndexError):
         m.check_timesteps(wait=True)
+    # strict mode: the offending call itself raises, as in the reference (one rendezvous per call)
+    m.strict_timesteps = True
+    with pytest.raises(IndexError, match="121"):
+        m.q(x, bad, noise=noise)
+    m.q(x, ok, noise=noise)                                        # nothing left pending
+    with pytest.raises(IndexError):
+        m.reverse_q(x, x, torch.tensor([0, 3, 4], device=dev), noise=noise)
 
 
 @pytest.mark.parametrize("c", [1, 3])
