@@ -74,7 +74,10 @@ def check_grads(named_grads, ref, l2_tol=0.2, cos_tol=0.98, prefix=""):
         gr = gr.detach().cpu()
         # the time-embedding MLPs see a spatial SUM of data-gradients with heavy cancellation, which amplifies
         # the relative rounding noise of its terms: wider bound for those 32 tensors
-        lt, ct = (0.35, 0.93) if "t_embeddings" in k else (l2_tol, cos_tol)
+        # the time-embedding MLPs see a spatial SUM of data-gradients with heavy cancellation, which amplifies the relative
+        # rounding noise of its bf16 terms (the sums themselves are taken from fp32 accumulators): measured worst 0.21 against
+        # the fp32 oracle at N = 3, 64x64; 0.08 against the bf16-storage oracle (test_gpu_configs.py holds those to the common bound)
+        lt, ct = (max(l2_tol, 0.25), min(cos_tol, 0.97)) if "t_embeddings" in k else (l2_tol, cos_tol)
         assert l2_err(gr, rf) < lt and cosine(gr, rf) > ct, (k, l2_err(gr, rf), cosine(gr, rf))
 
 
