@@ -39,6 +39,14 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     dev = torch.device("cuda:0")
     pool = [graphs._pool_stream(dev, k) for k in range(4)]
+    if os.environ.get('BIND', '0') == '1':      # fresh streams, each bound to a hardware queue by a first launch, in creation order
+        pool = []
+        for _ in range(4):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                torch.zeros(64, device=dev)
+            torch.cuda.synchronize()
+            pool.append(st)
     if os.environ.get('HIPRIO', '1') == '1':
         pool[2], pool[3] = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
     one = make(dev, B, pool[1], pool[0])
