@@ -184,6 +184,208 @@ extern "C" int ddpm_dwconv3x3_forward(const void* x, const float* w, const float
     return ddpm_check_launch("dwconv3x3");
 }
 
+// ---- depthwise 3x3 on the RAW result of the expansion convolution (inference on large images) ------------------------
+// x is the input of a GroupNorm + activation that has not been applied (conv_block.py:67-72 of the reference); affine =
+// fp32 [N][C][2] (scale, shift) per image and channel from ddpm_gn_fold_affine.  Applying them in the stencil's loads would
+// evaluate the activation 4.5 times per output, so the normalised rows go through LDS instead: a workgroup owns a band of
+// DWA_BAND image rows, keeps a ring of activated rows (every input row is normalised once, plus two halo rows per band) and
+// produces RS = 1 or 2 output rows per step with the arithmetic and the thread layout of dwconv3x3_kernel<4> (a step is
+// exactly one of its rounds of 256 work items, so the GroupNorm sums it leaves have the same layout).  While a step is
+// computed from LDS, the next step's raw rows are in flight; one barrier per step.
+#define DWA_BAND 16
+template <int RS>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_affine_kernel(const bf16* __restrict__ x, const float* __restrict__ affine, int act,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               bf16* __restrict__ y, int N, int H, int W, int C,
+                                                               float* __restrict__ part, int G, int PT) {
+    extern __shared__ __attribute__((aligned(16))) char s_ring[];      // [RING][W][C] bf16, then the reduction scratch
+    constexpr int RING = RS == 1 ? 4 : 8;
+    __shared__ float s_red[4 * 64 * 8];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 128];      // the taps [9][C] (read from here every step: held in registers they are 72 of them)
+    const int tid = threadIdx.x;
+    const int cvs = C / 8, wq = W / 4;
+    const int row_bytes = W * C * 2, row_vecs = W * cvs;             // RS * row_vecs = 1024: four vectors per thread and step
+    const int bands = H / DWA_BAND;
+    const int n = blockIdx.x / bands, y_begin = (blockIdx.x - n * bands) * DWA_BAND;
+    // this thread's four load slots of a step (vector index tid + 256 u of the RS rows): row in the step, byte offset in the row
+    int l_row[4], l_off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = tid + 256 * u;
+        l_row[u] = v / row_vecs;
+        l_off[u] = (v - l_row[u] * row_vecs) * 16;
+    }
+    // (scale, shift) of the eight channels of its load slots (256 % cvs == 0: the same channel vector in every slot)
+    float sc[8], sh[8];
+    {
+        const float* ap = affine + ((long long)n * C + (tid % cvs) * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x4 t4 = *(const f32x4*)(ap + j * 2);
+            sc[j] = t4[0]; sh[j] = t4[1]; sc[j + 1] = t4[2]; sh[j + 1] = t4[3];
+        }
+    }
+    const bf16* xn = x + (long long)n * H * W * C;
+    u32x4 ld[4];
+    bool ld_ok[4];
+    // raw vectors of image rows r0 .. r0 + RS - 1 (zeros outside the image: the convolution pads the ACTIVATED tensor)
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + l_row[u];
+            ld_ok[u] = r >= 0 && r < H;
+            const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
+            ld[u] = *(const u32x4*)((const char*)xn + (long long)rc * row_bytes + l_off[u]);
+        }
+    };
+    auto stash = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + l_row[u];
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f[2 * k] = __uint_as_float(ld[u][k] << 16) * sc[2 * k] + sh[2 * k];
+                f[2 * k + 1] = __uint_as_float(ld[u][k] & 0xffff0000u) * sc[2 * k + 1] + sh[2 * k + 1];
+            }
+            if (act == ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = act_fwd(f[j], ACT_GELU);
+            } else if (act == ACT_SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = act_fwd(f[j], ACT_SILU);
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = ld_ok[u] ? (bf16)f[j] : (bf16)0.f;
+            asm volatile("" : "+v"(o));            // one vector after the other: four interleaved activation chains do not fit the registers
+            *(bf16x8*)(s_ring + ((r + RING) & (RING - 1)) * row_bytes + l_off[u]) = o;
+        }
+    };
+    // the thread's work item of a step: the layout of dwconv3x3_kernel<4> (channel vector fastest, then x group, then row)
+    const int cv = tid % cvs, xr = tid / cvs;
+    const int wx = (xr % wq) * 4, ry = xr / wq;                      // ry < RS
+    const int c = cv * 8;
+    float bq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bq[j] = bias ? bias[c + j] : 0.f;
+    for (int i = tid; i < 9 * C; i += 256) s_w[i] = w[i];
+
+    // ---- band prologue: rows y_begin - 1 .. y_begin + RS (the first step's inputs); RS + 2 rows = up to two fetch rounds
+#pragma unroll 1
+    for (int r0 = y_begin - 1; r0 <= y_begin + RS; r0 += RS) { fetch(r0); stash(r0); }
+    __syncthreads();
+#pragma unroll 1
+    for (int y0 = y_begin; y0 < y_begin + DWA_BAND; y0 += RS) {
+        const bool more = y0 + RS < y_begin + DWA_BAND;
+        if (more) fetch(y0 + RS + 1);                                // rows y0 + RS + 1 .. y0 + 2 RS: new for the next step
+        const int hy = y0 + ry;
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[q][j] = bq[j];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const char* row = s_ring + ((hy + kh - 1 + RING) & (RING - 1)) * row_bytes + c * 2;
+            float wk[3][8];                                          // the kernel row's taps
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const f32x4 w0 = *(const f32x4*)(s_w + (kh * 3 + kw) * C + c), w1 = *(const f32x4*)(s_w + (kh * 3 + kw) * C + c + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wk[kw][j] = w0[j]; wk[kw][4 + j] = w1[j]; }
+            }
+#pragma unroll
+            for (int pq = 0; pq < 6; ++pq) {
+                const int ix = wx + pq - 1;
+                const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                u32x4 uv = *(const u32x4*)(row + ixc * C * 2);
+                if (pq == 0 || pq == 5) {
+                    const bool ok = ix >= 0 && ix < W;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) uv[k] = ok ? uv[k] : 0u;
+                }
+                float f[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(uv[k] << 16); f[2 * k + 1] = __uint_as_float(uv[k] & 0xffff0000u); }
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw) {
+                    const int q = pq - kw;
+                    if (q < 0 || q >= 4) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[q][j] += f[j] * wk[kw][j];
+                }
+            }
+        }
+        float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[q][j];
+            *(bf16x8*)(y + (((long long)n * H + hy) * W + wx + q) * C + c) = o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+        }
+        // the step's GroupNorm sums, exactly as dwconv3x3_kernel<4, true> leaves them for its round
+        for (int o = cvs; o < 64; o <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { st_s[q] += __shfl_xor(st_s[q], o); st_ss[q] += __shfl_xor(st_ss[q], o); }
+        }
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane < cvs) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s_red[(wv * cvs + lane) * 8 + q] = st_s[q]; s_red[(wv * cvs + lane) * 8 + 4 + q] = st_ss[q]; }
+        }
+        if (more) stash(y0 + RS + 1);                                // (slots of rows no step before the next one reads)
+        __syncthreads();
+        const int cpg = C / G;
+        if (tid < G) {
+            float S = 0.f, SS = 0.f;
+            for (int c2 = tid * cpg / 2; c2 < (tid + 1) * cpg / 2; ++c2) {
+                const int col = c2 >> 2, q = c2 & 3;
+#pragma unroll
+                for (int wq_ = 0; wq_ < 4; ++wq_) { S += s_red[(wq_ * cvs + col) * 8 + q]; SS += s_red[(wq_ * cvs + col) * 8 + 4 + q]; }
+            }
+            float* o = part + (((long long)n * G + tid) * PT + y0 / RS) * 2;
+            o[0] = S; o[1] = SS;
+        }
+        __syncthreads();                                             // s_red is rewritten by the next step
+    }
+}
+
+// 1 where ddpm_dwconv3x3_forward_affine takes the shape: rows of 128 or 256 work items (4 pixels x 8 channels each), bands of
+// DWA_BAND rows, and the conditions of the GroupNorm sums (ddpm_dwconv3x3_stat_parts)
+extern "C" int ddpm_dwconv3x3_affine_supported(int N, int H, int W, int C, int groups) {
+    if (ddpm_dwconv3x3_stat_parts(N, H, W, C, groups) <= 0 || W % 4 || H % DWA_BAND) return 0;
+    const int items = (W / 4) * (C / 8);
+    if ((items != 128 && items != 256) || C > 128) return 0;
+    const int rs = 256 / items;
+    return ((rs == 1 ? 4 : 8) * W * C * 2 <= 128 * 1024 && (long long)N * (H / DWA_BAND) < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int ddpm_dwconv3x3_forward_affine(const void* x, const float* affine, int act, const float* w, const float* bias, void* y, int N,
+                                             int H, int W, int C, int groups, float* part, ddpm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DDPM_REQUIRE(x && affine && w && y && part, "dwconv (normalise on load): null pointer");
+    DDPM_REQUIRE(act == ACT_NONE || act == ACT_GELU || act == ACT_SILU, "dwconv (normalise on load): activation none / gelu / silu");
+    DDPM_REQUIRE(ddpm_dwconv3x3_affine_supported(N, H, W, C, groups), "dwconv (normalise on load): unsupported shape N=%d %dx%d C=%d groups=%d (ask ddpm_dwconv3x3_affine_supported first)", N, H, W, C, groups);
+    const int PT = ddpm_dwconv3x3_stat_parts(N, H, W, C, groups);
+    const int rs = 256 / ((W / 4) * (C / 8));
+    const int lds = (rs == 1 ? 4 : 8) * W * C * 2;
+    const dim3 grid((unsigned)(N * (H / DWA_BAND)));
+    if (rs == 1) {
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute((const void*)dwconv3x3_affine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return ddpm_check_launch("dwconv: raise dynamic LDS limit"); attr = true; }
+        hipLaunchKernelGGL((dwconv3x3_affine_kernel<1>), grid, dim3(256), lds, stream, (const bf16*)x, affine, act, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
+    } else {
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute((const void*)dwconv3x3_affine_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return ddpm_check_launch("dwconv: raise dynamic LDS limit"); attr = true; }
+        hipLaunchKernelGGL((dwconv3x3_affine_kernel<2>), grid, dim3(256), lds, stream, (const bf16*)x, affine, act, w, bias, (bf16*)y, N, H, W, C, part, groups, PT);
+    }
+    return ddpm_check_launch("dwconv3x3 (normalise on load)");
+}
+
 // part[b][t][c]: t < 9: sum over the block's pixel strip of dy[n,h,w,c] * x[n,h+kh-1,w+kw-1,c]; t = 9: sum of dy.
 // Thread layout: 256 threads = (256/cvs) pixel lanes x cvs channel vectors (cvs = C/8, a power of two <= 64).
 // Lanes of a wave that share a channel vector are combined with shuffles, the four waves through LDS; the

@@ -185,6 +185,7 @@ class UNetEngine:
         self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.conv_stats = os.environ.get("DDPM_CONV_STATS", "1") != "0"   # large images: GroupNorm sums from the convolution's tiles
+        self.dw_on_load = os.environ.get("DDPM_DW_ON_LOAD", "1") != "0"      # inference, large images: the expansion's GroupNorm + act in the depthwise loader
         self.norm_on_load = os.environ.get("DDPM_NORM_ON_LOAD", "1") != "0"  # inference, large images: GroupNorm + act in the consumer's loader
         # inference: the low-resolution stages as up to three launches with the activations resident in LDS (csrc/unet_lds.hip).
         # Off unless asked for (DDPM_LDS=1): at the benchmarked batch sizes the per-layer kernels are faster (a workgroup that
@@ -678,7 +679,27 @@ class UNetEngine:
                         xin.g = dx
                     tape.append(bwd)
                 return out
-            e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
+            if (tape is None and m_in is None and m_e is None and m_d is None and self.conv_stats and self.norm_on_load and self.dw_on_load
+                    and sp.act in _LOADER_ACTS and act_scalar(act_site(pre + "expansion.2"), sp.act) is None
+                    and act_scalar(act_site(pre + "depthwise.2"), sp.act) is None):
+                # inference on large images: BOTH inner GroupNorms run in their consumer's loader.  The expansion's result stays
+                # raw as well: the depthwise kernel normalises each of its rows once on the way into an LDS ring
+                g1, g2 = pre + "expansion.2", pre + "depthwise.2"
+                raw_e = torch.empty(n, hh, ww, ech, device=dev, dtype=BF16)
+                # (a workgroup of that kernel owns 16 image rows: it needs a batch that gives every CU two of them)
+                if n * (hh // 16) >= 512 and ops.dwconv3x3_affine_supported(raw_e, sp.groups):
+                    raw_e, spart1 = ops.conv_forward(K11, xin.v, wc.fwd[ne], P[ne + ".bias"], ech, out=raw_e, gn_part_groups=sp.groups)
+                    if spart1 is not None:
+                        _, aff1 = ops.gn_fold_affine(spart1, P[g1 + ".weight"], P[g1 + ".bias"], hh * ww)
+                        raw_d, spart2 = ops.dwconv3x3_affine(raw_e, aff1, sp.act, wc.dw[nd], P[nd + ".bias"], sp.groups)
+                        _, aff2 = ops.gn_fold_affine(spart2, P[g2 + ".weight"], P[g2 + ".bias"], hh * ww)
+                        return conv_unit(pre + "projection.1", Var(raw_d), norm=pre + "projection.2", groups=sp.groups, act=0, res=xin,
+                                         in_affine=(aff2, sp.act))
+                    e = Var(ops.gn_act_forward(raw_e, P[g1 + ".weight"], P[g1 + ".bias"], sp.groups, sp.act)[0])
+                else:
+                    e = conv_unit(pre + "expansion.1", xin, norm=g1, groups=sp.groups, act=sp.act)
+            else:
+                e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
             if (tape is None and m_d is None and self.conv_stats and self.norm_on_load and sp.act in _LOADER_ACTS
                     and act_scalar(act_site(pre + "depthwise.2"), sp.act) is None):
                 # inference on large images: the depthwise result stays raw; its GroupNorm + activation run in the loader of

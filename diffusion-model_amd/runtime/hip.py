@@ -158,6 +158,8 @@ _PROTOS = {
     "ddpm_dwconv3x3_forward": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_stat_parts": ([_i, _i, _i, _i, _i], _i),
     "ddpm_dwconv3x3_forward_stats": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "ddpm_dwconv3x3_affine_supported": ([_i, _i, _i, _i, _i], _i),
+    "ddpm_dwconv3x3_forward_affine": ([_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "ddpm_dwconv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "ddpm_dwconv3x3_wgrad_blocks": ([_i, _i, _i, _i], _i),
     "ddpm_reduce_rows": ([_vp, _vp, _vp, _i, _i, _vp], _i),

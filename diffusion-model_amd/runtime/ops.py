@@ -549,6 +549,26 @@ def dwconv3x3(x: Tensor, w9c: Tensor, bias: Optional[Tensor], out: Optional[Tens
     return (out, None) if gn_part_groups > 0 else out
 
 
+def dwconv3x3_affine_supported(x: Tensor, groups: int) -> bool:
+    n, h, w, c = x.shape
+    return bool(hip.lib().ddpm_dwconv3x3_affine_supported(n, h, w, c, groups))
+
+
+def dwconv3x3_affine(x: Tensor, affine: Tensor, act: int, w9c: Tensor, bias: Optional[Tensor], groups: int):
+    """Depthwise 3x3 of act(x * scale + shift): x = the RAW NHWC bf16 input of a GroupNorm + activation that has not been applied,
+    affine = fp32 [N][C][2] from gn_fold_affine (inference on large images; dwconv3x3_affine_supported says where).  Returns
+    (y, part): the raw result and its GroupNorm partial sums fp32 [N][groups][parts][2]."""
+    n, h, w, c = x.shape
+    assert x.dtype == BF16 and x.is_contiguous() and w9c.shape == (9, c) and affine.shape == (n, c, 2) and affine.dtype == torch.float32
+    parts = hip.lib().ddpm_dwconv3x3_stat_parts(n, h, w, c, groups)
+    out = torch.empty_like(x)
+    part = torch.empty(n, groups, parts, 2, device=x.device, dtype=torch.float32)
+    _launch("dwconv3x3_kernel", lambda: (_nb(x, w9c, bias, out, affine), 18.0 * x.numel(), f"{h}x{w} C{c} normalise-on-load"),
+            lambda: hip.call("ddpm_dwconv3x3_forward_affine", hip.ptr(x), hip.ptr(affine), act, hip.ptr(w9c), hip.ptr(bias), hip.ptr(out),
+                             n, h, w, c, groups, hip.ptr(part), hip.stream()))
+    return out, part
+
+
 def dwconv3x3_wgrad_blocks(n: int, h: int, w: int, c: int) -> int:
     return hip.lib().ddpm_dwconv3x3_wgrad_blocks(n, h, w, c)
 

@@ -288,6 +288,14 @@ int ddpm_dwconv3x3_forward_stats(const void* x, const float* w, const float* bia
                                  int groups, float* part, ddpm_stream_t stream);
 /* Per-workgroup partial sums of the depthwise weight/bias gradient: part[b][t][c], t = 0..8 the taps of
  * dw (sum dy * shifted x), t = 9 the bias (sum dy); b < ddpm_dwconv3x3_wgrad_blocks(N,H,W,C).  Every element is written. */
+/* Inference on large images: x is the RAW result of the expansion convolution, whose GroupNorm + activation (conv_block.py:67-72)
+ * has not been applied; affine = fp32 [N][C][2] (scale, shift) from ddpm_gn_fold_affine, act = none / gelu / silu.  The kernel
+ * normalises every input row once on its way into an LDS ring and runs the stencil from there: the GroupNorm launch and its
+ * output tensor disappear.  Leaves the GroupNorm sums of its own result like ddpm_dwconv3x3_forward_stats (same layout).
+ * Shapes: ddpm_dwconv3x3_affine_supported() (rows of 128 / 256 work items, H a multiple of 16, C <= 128). */
+int ddpm_dwconv3x3_affine_supported(int N, int H, int W, int C, int groups);
+int ddpm_dwconv3x3_forward_affine(const void* x, const float* affine, int act, const float* w, const float* bias, void* y, int N, int H,
+                                  int W, int C, int groups, float* part, ddpm_stream_t stream);
 int ddpm_dwconv3x3_wgrad(const void* x, const void* dy, float* part, int N, int H, int W, int C, ddpm_stream_t stream);
 int ddpm_dwconv3x3_wgrad_blocks(int N, int H, int W, int C);
 

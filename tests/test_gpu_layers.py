@@ -112,6 +112,38 @@ def test_depthwise_leaves_groupnorm_sums_for_large_images(dev, n, c, h, w_, grou
         assert none is None
 
 
+@pytest.mark.parametrize("n,c,h,w_,groups,act", [(3, 64, 64, 64, 16, "gelu"), (2, 64, 128, 128, 16, "silu"), (2, 128, 64, 64, 16, "gelu"),
+                                                  (1, 64, 32, 64, 16, "none"), (2, 32, 16, 128, 16, "gelu")])
+def test_depthwise_normalises_its_input_on_load(dev, n, c, h, w_, groups, act):
+    """Inference on large images: the depthwise kernel reads the RAW result of the expansion and applies GroupNorm + activation
+    on the way into its LDS row ring.  Against the two-launch path (GroupNorm launch, depthwise kernel with sums): the result
+    within one bf16 step of its scale, the GroupNorm sums it leaves equal to the sums of what it stored; against torch fp32
+    within the bf16 tolerance."""
+    x = r16(hash_normal((n, c, h, w_), 301) * 1.2 + 0.3)
+    gamma, beta = (1 + 0.3 * hash_normal((c,), 302)), (0.3 * hash_normal((c,), 303))
+    wt = hash_normal((c, 1, 3, 3), 304) / 3
+    bias = hash_normal((c,), 305) * 0.1
+    xd = nhwc(x, dev)
+    assert ops.dwconv3x3_affine_supported(xd, groups)
+    parts = 8
+    g = xd.float().view(n, parts, h * w_ // parts, groups, c // groups)
+    part = torch.stack([g.sum((2, 4)), (g * g).sum((2, 4))], -1).permute(0, 2, 1, 3).contiguous()
+    _, affine = ops.gn_fold_affine(part, gamma.to(dev), beta.to(dev), h * w_)
+    w9 = wt.view(c, 9).t().contiguous().to(dev)
+    y_gn, _ = ops.gn_act_forward(xd, gamma.to(dev), beta.to(dev), groups, hip.ACT[act])
+    ref_y, ref_part = ops.dwconv3x3(y_gn, w9, bias.to(dev), gn_part_groups=groups)
+    got, gpart = ops.dwconv3x3_affine(xd, affine, hip.ACT[act], w9, bias.to(dev), groups)
+    assert_rel(got.float().cpu(), ref_y.float().cpu(), 8e-3)
+    assert gpart.shape == ref_part.shape
+    gg = got.float().view(n, -1, groups, c // groups)
+    torch.testing.assert_close(gpart[..., 0].sum(2), gg.sum((1, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(gpart[..., 1].sum(2), (gg * gg).sum((1, 3)), rtol=1e-4, atol=1e-2)
+    a = (lambda v: v) if act == "none" else O.act_fn(act)
+    ref = F.conv2d(r16(a(F.group_norm(x, groups, gamma, beta, eps=1e-5))), wt, bias, padding=1, groups=c)
+    assert_rel(nchw(got), ref, 1e-2)
+    assert not ops.dwconv3x3_affine_supported(nhwc(r16(hash_normal((1, 64, 8, 8), 1)), dev), groups)
+
+
 WG_CASES = [
     (hip.CONV_3X3_S1, 2, 32, 32, 16, 16),
     (hip.CONV_3X3_S1, 3, 64, 32, 8, 8),
