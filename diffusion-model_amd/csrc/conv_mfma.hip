@@ -19,6 +19,8 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_
 int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream);    // conv_thin.hip
 int ddpm_conv_img_try(const ddpm_conv_desc* d, hipStream_t stream, int plain_too);   // conv_img.hip
 int ddpm_conv_pipe_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_pipe.hip
+int ddpm_conv_pw_stream_try(const ddpm_conv_desc* d, hipStream_t stream);   // conv_pw_stream.hip
+int ddpm_conv_pw_stream_tiles(const ddpm_conv_desc* d);
 
 struct ConvArgs {
     ConvGeom g;
@@ -439,8 +441,10 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
+    // pointwise convolutions of large images at large batch: the streaming kernel (weights in registers, no workgroup barrier)
+    if (const int rc = ddpm_conv_pw_stream_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_PW_STREAM; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     if (d->in_affine && !d->gn_part) {
-        // normalise-on-load exists in the general kernel only
+        // otherwise normalise-on-load exists in the general kernel only
         DDPM_REQUIRE(!d->gn_gamma && !d->gnb_raw, "conv: normalise-on-load does not combine with the fused GroupNorm launches");
         return conv_general(d, stream);
     }
@@ -498,13 +502,16 @@ extern "C" int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d) {
     if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->CoutW <= 0 || d->CoutW % 32) return 0;
     const int cpg = d->Cout / d->gn_part_groups;
     if (cpg < 2 || (cpg & (cpg - 1))) return 0;
+    // only where the GroupNorm that follows takes its many-workgroup path (more than 4096 vectors per image and channel slab,
+    // the rule of groupnorm.hip); smaller problems run the single-pass GroupNorm, which computes its own statistics
+    const int slab = d->Cout % 64 == 0 ? 64 : (d->Cout % 32 == 0 ? 32 : (d->Cout % 16 == 0 ? 16 : 8));
+    if (d->kind == CONV_1X1 && (long long)d->IH * d->IW * (slab / 8) > 4096 && d->IH > 8 && d->IW > 8) {
+        if (const int t = ddpm_conv_pw_stream_tiles(d)) return t;      // the streaming kernel: one slot per workgroup
+    }
     ConvCfg cfg; ConvGeom g;
     if (conv_pick(d, &cfg, &g) < 0) return 0;
     const int bn = 32 * cfg.nt * cfg.wn;
     if (bn % cpg || g.NB != 1 || g.GH % g.TH || g.GW % g.TW) return 0;
-    // only where the GroupNorm that follows takes its many-workgroup path (more than 4096 vectors per image and channel slab,
-    // the rule of groupnorm.hip); smaller problems run the single-pass GroupNorm, which computes its own statistics
-    const int slab = d->Cout % 64 == 0 ? 64 : (d->Cout % 32 == 0 ? 32 : (d->Cout % 16 == 0 ? 16 : 8));
     if ((long long)g.OH * g.OW * (slab / 8) <= 4096 || g.OH <= 8 || g.OW <= 8) return 0;
     return g.ncls * g.tiles_h * g.tiles_w;
 }

@@ -19,7 +19,7 @@ ACT_WITH_SCALAR = (10, 11)        # swish, hardswish: one learnable scalar per a
 CONV_3X3_S1, CONV_3X3_S2, CONV_1X1, CONVT_2X2_S2, DGRAD_3X3_S2, DGRAD_CONVT_2X2 = range(6)
 OUT_BF16_NHWC, OUT_F32_NCHW = 0, 1
 CONV_KERNEL_NAMES = {0: "conv_mfma_kernel", 1: "conv_mfma_kernel", 2: "conv_small_kernel", 3: "conv_thin_kernel", 4: "conv_img_kernel",
-                     5: "conv_pipe_kernel"}
+                     5: "conv_pipe_kernel", 6: "pw_stream_kernel"}
 
 _vp, _i, _f, _i64, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint32
 
@@ -144,6 +144,7 @@ _PROTOS = {
     "ddpm_conv_debug_tile": ([_i], _i),
     "ddpm_conv_last_kernel": ([], _i),
     "ddpm_conv_pipe_mode": ([_i], _i),
+    "ddpm_conv_pw_stream_mode": ([_i], _i),
     "ddpm_conv_gn_fusable": ([C.POINTER(ConvDesc)], _i),
     "ddpm_conv_gn_part_tiles": ([C.POINTER(ConvDesc)], _i),
     "ddpm_conv_gnb_fusable": ([C.POINTER(ConvDesc)], _i),
@@ -203,6 +204,8 @@ def lib():
         for name, (args, res) in _PROTOS.items():
             fn = getattr(_lib, name)
             fn.argtypes, fn.restype = args, res
+        if os.environ.get("DDPM_CONV_PW_STREAM", "1") == "0":     # A/B switch: never take the streaming pointwise kernel
+            _lib.ddpm_conv_pw_stream_mode(-1)
         if os.environ.get("DDPM_CONV_PIPE", "1") == "0":     # A/B switch: never take the pipelined wide-convolution kernel
             _lib.ddpm_conv_pipe_mode(-1)                      # (per thread: this one launches the forward passes)
     return _lib

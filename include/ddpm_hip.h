@@ -197,13 +197,19 @@ int ddpm_conv_debug_tile(int force);
  * the general tap-list kernel, the split-K kernel of 3x3 convolutions on 2x2 / 4x4 / 8x8 images, the vector-ALU kernel of the
  * image ends, or the whole-image kernel that finishes the unit's GroupNorm (or its backward) in the same launch. */
 enum { DDPM_CONV_KERNEL_NONE = 0, DDPM_CONV_KERNEL_GENERAL = 1, DDPM_CONV_KERNEL_SMALL = 2, DDPM_CONV_KERNEL_THIN = 3, DDPM_CONV_KERNEL_IMAGE = 4,
-       DDPM_CONV_KERNEL_PIPE = 5 /* the pipelined 256 x 128 tile kernel of deep, wide convolutions at large batch */ };
+       DDPM_CONV_KERNEL_PIPE = 5 /* the pipelined 256 x 128 tile kernel of deep, wide convolutions at large batch */,
+       DDPM_CONV_KERNEL_PW_STREAM = 6 /* the streaming kernel of pointwise convolutions on large images at large batch */ };
 int ddpm_conv_last_kernel(void);
 /* Test / measurement hook (no counterpart in the reference): the pipelined kernel (3x3 stride 1 on 4x4 / 8x8 / 16x16 images and
  * 1x1, input channels a multiple of 64, output channels a multiple of 128, plain epilogue) is taken by problem size
  * (mode 0: at least one 256-position tile per CU), wherever the shape allows (1) or never (-1).  Per calling thread; returns
  * the previous mode. */
 int ddpm_conv_pipe_mode(int mode);
+/* Test / measurement hook (no counterpart in the reference): the streaming kernel of pointwise convolutions (1x1, one input
+ * tensor of 32 / 64 / 128 channels, 32 / 64 / 128 output channels, at most 8192 weights, image area a multiple of 128, bias,
+ * normalise-on-load and per-tile GroupNorm sums only) is taken by problem size (mode 0: at least 256 K positions), wherever the
+ * shape allows (1) or never (-1).  Per calling thread; returns the previous mode. */
+int ddpm_conv_pw_stream_mode(int mode);
 
 /* ---- GroupNorm + activation (+ dropout mask, + residual) on NHWC bf16 (groupnorm.hip) ------------- */
 

@@ -520,6 +520,143 @@ def test_conv_normalises_and_activates_on_load(dev, n, ci, co, h, wd, groups, ac
     assert_rel(nchw(got), y_ref, 1e-2)
 
 
+@pytest.mark.parametrize("n,ci,co,h,wd,groups,act", [
+    (2, 32, 64, 128, 128, 16, None),           # expansion at the first stage: plain input, sums for the GroupNorm that follows
+    (3, 64, 32, 64, 64, 16, "gelu"),           # projection: the depthwise result normalised and activated on load
+    (2, 64, 128, 64, 32, 16, None),
+    (1, 128, 64, 32, 48, 4, "silu"),           # 16 channels per group; image area 1536 = 12 x 128 positions
+    (5, 32, 32, 32, 32, 16, "none"),
+    (2, 128, 32, 64, 64, 16, "gelu"),
+    (2, 32, 128, 16, 24, 8, None),             # three workgroups of 128 positions per image
+    (2, 64, 64, 128, 64, 32, "gelu"),          # 2 channels per group
+])
+def test_pointwise_streaming_kernel(dev, n, ci, co, h, wd, groups, act):
+    """The streaming kernel of pointwise convolutions (weights in registers, wave-private output tiles), forced onto small
+    problems: the raw result against the general kernel on the same operands (both round one fp32 dot product per element, in a
+    different order: one bf16 step of the tensor's scale) and against torch fp32; the per-workgroup GroupNorm sums against the
+    sums of the stored tensor, and the GroupNorm that consumes them against the two-pass GroupNorm."""
+    from oracle import ref_cpu as O
+    lib = hip.lib()
+    x = r16(hash_normal((n, ci, h, wd), 191) * 1.2 + 0.3)
+    w = r16(hash_normal((co, ci, 1, 1), 192) * (1.0 / ci) ** 0.5)
+    b = hash_normal((co,), 193) * 0.3
+    gamma, beta = (1 + 0.3 * hash_normal((ci,), 194)), (0.3 * hash_normal((ci,), 195))
+    xd, wp, bd = nhwc(x, dev), pack.pack_fwd(hip.CONV_1X1, w.to(dev)), b.to(dev)
+    in_aff = None
+    x_eff = x
+    if act is not None:
+        gin = 16
+        g = xd.float().view(n, 4, h * wd // 4, gin, ci // gin)
+        part_in = torch.stack([g.sum((2, 4)), (g * g).sum((2, 4))], -1).permute(0, 2, 1, 3).contiguous()
+        _, affine = ops.gn_fold_affine(part_in, gamma.to(dev), beta.to(dev), h * wd)
+        in_aff = (affine, hip.ACT[act] if act != "none" else 0)
+        a = (lambda v: v) if act == "none" else O.act_fn(act)
+        x_eff = r16(a(F.group_norm(x, gin, gamma, beta, eps=1e-5)))
+    prev = lib.ddpm_conv_pw_stream_mode(1)
+    try:
+        got, part = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff, gn_part_groups=groups)
+        assert lib.ddpm_conv_last_kernel() == 6
+        plain = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff)
+        assert lib.ddpm_conv_last_kernel() == 6
+        lib.ddpm_conv_pw_stream_mode(-1)
+        ref = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff)
+        assert lib.ddpm_conv_last_kernel() == 1
+    finally:
+        lib.ddpm_conv_pw_stream_mode(prev)
+    assert torch.equal(got, plain)
+    assert_rel(got.float().cpu(), ref.float().cpu(), 8e-3)
+    assert_rel(nchw(got), F.conv2d(x_eff, w, b), 1e-2)
+    if h * wd * (co // 8 if co < 64 else 8) > 4096 and h > 8 and wd > 8:
+        assert part is not None and part.shape[:2] == (n, groups) and (h * wd) % part.shape[2] == 0
+        gg = got.float().view(n, -1, groups, co // groups)
+        torch.testing.assert_close(part[..., 0].sum(2), gg.sum((1, 3)), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(part[..., 1].sum(2), (gg * gg).sum((1, 3)), rtol=1e-4, atol=1e-2)
+        go, bo = (1 + 0.3 * hash_normal((co,), 196)).to(dev), (0.3 * hash_normal((co,), 197)).to(dev)
+        y, stats = ops.gn_act_forward(got, go, bo, groups, hip.ACT["gelu"], stat_part=part)
+        y2, stats2 = ops.gn_act_forward(got, go, bo, groups, hip.ACT["gelu"])
+        torch.testing.assert_close(stats, stats2, rtol=1e-5, atol=1e-6)
+        assert_rel(y.float().cpu(), y2.float().cpu(), 8e-3)
+    else:
+        assert part is None
+
+
+@pytest.mark.parametrize("n,ci,co,h,act", [(128, 32, 64, 128, None), (64, 64, 32, 128, "gelu"), (160, 64, 128, 64, None), (256, 128, 64, 32, "silu")])
+def test_pointwise_streaming_kernel_at_sampling_batch(dev, n, ci, co, h, act):
+    """The sizes the dispatcher sends there by itself (256 K positions and more: workgroups of 256 .. 1024 positions), against
+    the general kernel on the device: result within one bf16 step of the scale, partial sums against the stored tensor."""
+    lib = hip.lib()
+    gen = torch.Generator(device=dev).manual_seed(7)
+    xd = (torch.randn(n, h, h, ci, device=dev, generator=gen) * 1.1 + 0.2).bfloat16()
+    wp = pack.pack_fwd(hip.CONV_1X1, torch.randn(co, ci, 1, 1, device=dev, generator=gen) / ci ** 0.5)
+    bd = torch.randn(co, device=dev, generator=gen) * 0.3
+    in_aff = None
+    if act is not None:
+        affine = torch.stack([torch.rand(n, ci, device=dev, generator=gen) + 0.5, torch.randn(n, ci, device=dev, generator=gen) * 0.3], 2).contiguous()
+        in_aff = (affine, hip.ACT[act])
+    got, part = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff, gn_part_groups=16)
+    assert lib.ddpm_conv_last_kernel() == 6 and part is not None and part.shape[2] <= h * h // 128
+    prev = lib.ddpm_conv_pw_stream_mode(-1)
+    try:
+        ref = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff)
+    finally:
+        lib.ddpm_conv_pw_stream_mode(prev)
+    scale = ref.float().abs().max().item()
+    assert (got.float() - ref.float()).abs().max().item() <= 8e-3 * scale
+    gg = got.float().view(n, -1, 16, co // 16)
+    torch.testing.assert_close(part[..., 0].sum(2), gg.sum((1, 3)), rtol=1e-4, atol=5e-2)
+    torch.testing.assert_close(part[..., 1].sum(2), (gg * gg).sum((1, 3)), rtol=1e-4, atol=5e-2)
+
+
+@pytest.mark.parametrize("n,ci,co,h,act", [(2, 32, 64, 64, None), (3, 64, 32, 32, "gelu"), (1, 128, 64, 16, None)])
+def test_pointwise_streaming_kernel_with_input_dropout(dev, n, ci, co, h, act):
+    """the block input's dropout mask (one keep bit per element, applied after the normalise-on-load) in the streaming kernel:
+    bit-equal to the general kernel's mask handling up to the dot product's rounding, and against torch fp32"""
+    from oracle import ref_cpu as O
+    lib = hip.lib()
+    x = r16(hash_normal((n, ci, h, h), 291))
+    w = r16(hash_normal((co, ci, 1, 1), 292) * (1.0 / ci) ** 0.5)
+    b = hash_normal((co,), 293) * 0.3
+    keep = hash_uniform((n, h, h, ci), 294) < 0.8
+    kb = (keep.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).to(dev)
+    xd, wp, bd = nhwc(x, dev), pack.pack_fwd(hip.CONV_1X1, w.to(dev)), b.to(dev)
+    in_aff, x_eff = None, x
+    if act is not None:
+        sc, sh = hash_uniform((n, ci), 295) + 0.5, hash_normal((n, ci), 296) * 0.3
+        in_aff = (torch.stack([sc, sh], 2).contiguous().to(dev), hip.ACT[act])
+        x_eff = r16(O.act_fn(act)(x * sc[:, :, None, None] + sh[:, :, None, None]))
+    x_eff = r16(x_eff * keep.permute(0, 3, 1, 2) / 0.8)
+    prev = lib.ddpm_conv_pw_stream_mode(1)
+    try:
+        got = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff, in_mask=kb, in_scale=1 / 0.8)
+        assert lib.ddpm_conv_last_kernel() == 6
+        lib.ddpm_conv_pw_stream_mode(-1)
+        ref = ops.conv_forward(hip.CONV_1X1, xd, wp, bd, co, in_affine=in_aff, in_mask=kb, in_scale=1 / 0.8)
+    finally:
+        lib.ddpm_conv_pw_stream_mode(prev)
+    assert_rel(got.float().cpu(), ref.float().cpu(), 8e-3)
+    assert_rel(nchw(got), F.conv2d(x_eff, w, b), 1e-2)
+
+
+def test_pointwise_streaming_kernel_declines_what_it_does_not_cover(dev):
+    """other shapes, fused epilogues and small problems stay on the other kernels (mode 0 = by size)"""
+    lib = hip.lib()
+    prev = lib.ddpm_conv_pw_stream_mode(1)
+    try:
+        for ci, co, h, kw in ((256, 64, 16, {}), (128, 128, 16, {}), (64, 32, 10, {}), (64, 32, 16, {"act": hip.ACT["gelu"]}), (64, 32, 16, {"res": True})):
+            x = torch.zeros(2, h, h, ci, device=dev, dtype=torch.bfloat16)
+            w = pack.pack_fwd(hip.CONV_1X1, torch.zeros(co, ci, 1, 1, device=dev))
+            if kw.get("res"):
+                kw = {"res": torch.zeros(2, h, h, co, device=dev, dtype=torch.bfloat16)}
+            ops.conv_forward(hip.CONV_1X1, x, w, None, co, **kw)
+            assert lib.ddpm_conv_last_kernel() != 6, (ci, co, h, kw)
+        lib.ddpm_conv_pw_stream_mode(0)
+        x = torch.zeros(2, 64, 64, 32, device=dev, dtype=torch.bfloat16)
+        ops.conv_forward(hip.CONV_1X1, x, pack.pack_fwd(hip.CONV_1X1, torch.zeros(64, 32, 1, 1, device=dev)), None, 64)
+        assert lib.ddpm_conv_last_kernel() != 6            # 8 K positions: below the size rule
+    finally:
+        lib.ddpm_conv_pw_stream_mode(prev)
+
+
 PIPE_CASES = [
     # kind, N, C0, C1, Cout, W, act, with residual
     (hip.CONV_3X3_S1, 3, 128, 0, 128, 16, "none", False),
