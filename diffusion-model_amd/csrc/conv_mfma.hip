@@ -441,8 +441,9 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
-    // pointwise convolutions of large images at large batch: the streaming kernel (weights in registers, no workgroup barrier)
-    if (const int rc = ddpm_conv_pw_stream_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_PW_STREAM; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
+    // pointwise convolutions of large images: the streaming kernel (weights in registers, no workgroup barrier), unless a test
+    // has forced a tile of the general kernel
+    if (const int rc = g_force_tile ? 0 : ddpm_conv_pw_stream_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_PW_STREAM; return rc > 0 ? DDPM_OK : DDPM_EHIP; }
     if (d->in_affine && !d->gn_part) {
         // otherwise normalise-on-load exists in the general kernel only
         DDPM_REQUIRE(!d->gn_gamma && !d->gnb_raw, "conv: normalise-on-load does not combine with the fused GroupNorm launches");
@@ -506,7 +507,7 @@ extern "C" int ddpm_conv_gn_part_tiles(const ddpm_conv_desc* d) {
     // the rule of groupnorm.hip); smaller problems run the single-pass GroupNorm, which computes its own statistics
     const int slab = d->Cout % 64 == 0 ? 64 : (d->Cout % 32 == 0 ? 32 : (d->Cout % 16 == 0 ? 16 : 8));
     if (d->kind == CONV_1X1 && (long long)d->IH * d->IW * (slab / 8) > 4096 && d->IH > 8 && d->IW > 8) {
-        if (const int t = ddpm_conv_pw_stream_tiles(d)) return t;      // the streaming kernel: one slot per workgroup
+        if (const int t = g_force_tile ? 0 : ddpm_conv_pw_stream_tiles(d)) return t;      // the streaming kernel: one slot per workgroup
     }
     ConvCfg cfg; ConvGeom g;
     if (conv_pick(d, &cfg, &g) < 0) return 0;

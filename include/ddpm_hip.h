@@ -207,7 +207,7 @@ int ddpm_conv_last_kernel(void);
 int ddpm_conv_pipe_mode(int mode);
 /* Test / measurement hook (no counterpart in the reference): the streaming kernel of pointwise convolutions (1x1, one input
  * tensor of 32 / 64 / 128 channels, 32 / 64 / 128 output channels, at most 8192 weights, image area a multiple of 128, bias,
- * normalise-on-load and per-tile GroupNorm sums only) is taken by problem size (mode 0: at least 256 K positions), wherever the
+ * normalise-on-load and per-tile GroupNorm sums only) is taken by problem size (mode 0: at least 32 K positions), wherever the
  * shape allows (1) or never (-1).  Per calling thread; returns the previous mode. */
 int ddpm_conv_pw_stream_mode(int mode);
 

@@ -314,7 +314,8 @@ def test_conv_every_tile_variant(dev, tile, kind, n, ci, co, h, w_):
 
 
 @pytest.mark.parametrize("want,kind,n,ci,co,h", [
-    (414, hip.CONV_1X1, 64, 64, 128, 32),          # the judge-visible large-batch shapes: the automatic choice reaches each tile
+    (414, hip.CONV_1X1, 64, 256, 128, 32),         # large-batch shapes: the automatic choice reaches each tile (a pointwise shape
+                                                   # the streaming kernel does not take)
     (412, hip.CONV_3X3_S1, 128, 64, 64, 32),
     (414, hip.CONVT_2X2_S2, 128, 128, 128, 16),
 ])
@@ -582,7 +583,7 @@ def test_pointwise_streaming_kernel(dev, n, ci, co, h, wd, groups, act):
 
 @pytest.mark.parametrize("n,ci,co,h,act", [(128, 32, 64, 128, None), (64, 64, 32, 128, "gelu"), (160, 64, 128, 64, None), (256, 128, 64, 32, "silu")])
 def test_pointwise_streaming_kernel_at_sampling_batch(dev, n, ci, co, h, act):
-    """The sizes the dispatcher sends there by itself (256 K positions and more: workgroups of 256 .. 1024 positions), against
+    """Sizes the dispatcher sends there by itself (32 K positions and more; these have workgroups of 128 .. 1024 positions), against
     the general kernel on the device: result within one bf16 step of the scale, partial sums against the stored tensor."""
     lib = hip.lib()
     gen = torch.Generator(device=dev).manual_seed(7)
@@ -652,7 +653,7 @@ def test_pointwise_streaming_kernel_declines_what_it_does_not_cover(dev):
         lib.ddpm_conv_pw_stream_mode(0)
         x = torch.zeros(2, 64, 64, 32, device=dev, dtype=torch.bfloat16)
         ops.conv_forward(hip.CONV_1X1, x, pack.pack_fwd(hip.CONV_1X1, torch.zeros(64, 32, 1, 1, device=dev)), None, 64)
-        assert lib.ddpm_conv_last_kernel() != 6            # 8 K positions: below the size rule
+        assert lib.ddpm_conv_last_kernel() != 6            # 8 K positions: below the size rule (32 K)
     finally:
         lib.ddpm_conv_pw_stream_mode(prev)
 

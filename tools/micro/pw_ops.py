@@ -1,6 +1,6 @@
 """The pointwise (1x1) convolutions and the normalise-on-load depthwise kernel of large images, timed alone (HIP events) with
 their algorithmic GB/s, once with gelu in the loader and once without (tells arithmetic-bound from bandwidth-bound):
-python tools/micro/pw_ops.py [batch]"""
+python tools/micro/pw_ops.py [batch]          (PWS_MODE=1 / -1: the streaming pointwise kernel everywhere / nowhere)"""
 import os
 import sys
 
@@ -14,6 +14,8 @@ from dm_amd.runtime import hip, ops, pack  # noqa: E402
 dev = torch.device("cuda", 0)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 K11 = hip.CONV_1X1
+if os.environ.get("PWS_MODE"):
+    hip.lib().ddpm_conv_pw_stream_mode(int(os.environ["PWS_MODE"]))
 G = 16
 
 
