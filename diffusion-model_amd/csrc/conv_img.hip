@@ -47,6 +47,7 @@ struct ImgArgs {
     const bf16* w; const float* bias; int w_rows, Cin;
     bf16* out; const bf16* res; float* sum_out; int Cout, out_cs, act;
     const float* gn_gamma; const float* gn_beta; bf16* gn_out; float* gn_stats; const bf16* gn_res; int gn_groups, gn_act; float gn_eps;
+    const float* gn_act_beta;        // swish / hardswish: the activation's learnable scalar (else null)
     const bf16* gnb_raw; const float* gnb_gamma; const float* gnb_beta; const float* gnb_stats; float* gnb_part; bf16* gnb_draw;
     int gnb_groups, gnb_act;
     int p_shift, gw_shift;         // log2 of positions per image (per class) and of the position grid's width
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
     const int gpt_shift2 = MODE == IMG_FWD_GN ? __builtin_ctz(BN) - a.gn_cpg_shift : 0;
     act_dispatch(MODE == IMG_FWD_GN ? a.gn_act : ACT_NONE, [&](auto atag) {
     const int act_c = ACT_OF(atag, a.gn_act);
+    const float act_b = (MODE == IMG_FWD_GN && a.gn_act_beta) ? *a.gn_act_beta : 1.f;
 #pragma unroll 2
     for (int it = tid; it < ROWS * (BN / 8); it += T) {
         const int row = it / (BN / 8), part = it - row * (BN / 8);
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(T) void conv_img_kernel(const ImgArgs a) {
                 const float mean = s_st[pair * 2], rstd = s_st[pair * 2 + 1];
                 const float gm = j < 4 ? g0[j & 3] : g1[j & 3], bt = j < 4 ? b0[j & 3] : b1[j & 3];
                 const float sc = gm * rstd, sh = bt - mean * sc;
-                y[j] = (bf16)(act_fwd((float)v[j] * sc + sh, act_c) + (float)rv[j]);
+                y[j] = (bf16)(act_fwd((float)v[j] * sc + sh, act_c, act_b) + (float)rv[j]);
             }
             *(bf16x8*)(a.gn_out + e) = y;
         }
@@ -776,7 +778,7 @@ static bool img_plan(const ddpm_conv_desc* d, ImgPlan* p) {
     a.w = (const bf16*)d->w; a.bias = d->bias; a.w_rows = d->w_rows; a.Cin = Cin;
     a.out = (bf16*)d->out; a.res = (const bf16*)d->res; a.sum_out = d->sum_out; a.Cout = d->Cout; a.out_cs = d->out_cs; a.act = d->act;
     a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_out = (bf16*)d->gn_out; a.gn_stats = d->gn_stats; a.gn_res = (const bf16*)d->gn_res;
-    a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps;
+    a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps; a.gn_act_beta = d->gn_act_beta;
     a.gnb_raw = (const bf16*)d->gnb_raw; a.gnb_gamma = d->gnb_gamma; a.gnb_beta = d->gnb_beta; a.gnb_stats = d->gnb_stats;
     a.gnb_part = d->gnb_part; a.gnb_draw = (bf16*)d->gnb_draw; a.gnb_groups = d->gnb_groups; a.gnb_act = d->gnb_act;
     a.p_shift = ilog2_exact(P); a.gw_shift = ilog2_exact(g.GW);

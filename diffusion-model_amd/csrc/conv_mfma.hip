@@ -441,6 +441,7 @@ extern "C" int ddpm_conv_forward(const ddpm_conv_desc* d, ddpm_stream_t stream_)
                  "conv: NHWC output channel stride %d must be a multiple of 8 >= Cout", d->out_cs);
     DDPM_REQUIRE(!(d->kind == DGRAD_CONVT_2X2) || (d->IH % 2 == 0 && d->IW % 2 == 0), "conv: convT data-gradient needs even dims");
     DDPM_REQUIRE((long long)d->N * d->IH * d->IW * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 31), "conv: tensor too large for 32-bit pixel index");
+    DDPM_REQUIRE(!(d->gn_gamma && ACT_HAS_BETA(d->gn_act)) || d->gn_act_beta, "conv: a fused GroupNorm with swish / hardswish needs the activation's scalar (gn_act_beta)");
     // pointwise convolutions of large images: the streaming kernel (weights in registers, no workgroup barrier), unless a test
     // has forced a tile of the general kernel
     if (const int rc = g_force_tile ? 0 : ddpm_conv_pw_stream_try(d, stream)) { g_last_kernel = DDPM_CONV_KERNEL_PW_STREAM; return rc > 0 ? DDPM_OK : DDPM_EHIP; }

@@ -24,6 +24,7 @@ struct SmallConvArgs {
     // optional fused GroupNorm + activation (+ residual) of the result: a tile holds whole images and whole groups
     const float* gn_gamma; const float* gn_beta; bf16* gn_out; float* gn_stats; const bf16* gn_res;
     int gn_groups, gn_act; float gn_eps;
+    const float* gn_act_beta;        // swish / hardswish: the activation's learnable scalar (else null)
     // optional GroupNorm + activation BACKWARD applied to the input on its way into LDS (data-gradient launches): in0 is then
     // the gradient of the normalised, activated tensor; the tile holds whole images and all channels, so the statistics of
     // the backward pass are complete inside the workgroup
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
         }
     }
     __syncthreads();
+    const float act_b = a.gn_act_beta ? *a.gn_act_beta : 1.f;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         if (!live[mb]) continue;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallConvArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float sc = gam[j] * rstd, sh = bet[j] - mean * sc;
-            float y = act_fwd(val[mb][j] * sc + sh, A >= 0 ? A : a.gn_act);
+            float y = act_fwd(val[mb][j] * sc + sh, A >= 0 ? A : a.gn_act, act_b);
             if (a.gn_res) y += (float)rv4[mb][j];
             o[j] = (bf16)y;
         }
@@ -376,7 +378,7 @@ static int small_gn_fusable(const ddpm_conv_desc* d) {
 
 // Whether the GroupNorm described by the gn_* fields can finish inside the convolution's launch.
 extern "C" int ddpm_conv_gn_fusable(const ddpm_conv_desc* d) {
-    if (d && ACT_HAS_BETA(d->gn_act)) return 0;
+    if (d && ACT_HAS_BETA(d->gn_act) && !d->gn_act_beta) return 0;    // swish / hardswish bring their learnable scalar
     return small_gn_fusable(d) || (d && ddpm_conv_img_fusable(d, 0));
 }
 
@@ -393,7 +395,7 @@ int ddpm_conv_small_try(const ddpm_conv_desc* d, hipStream_t stream) {
     a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out; a.res = (const bf16*)d->res; a.sum_out = d->sum_out;
     a.N = d->N; a.Cout = d->Cout; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act;
     a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_out = (bf16*)d->gn_out; a.gn_stats = d->gn_stats; a.gn_res = (const bf16*)d->gn_res;
-    a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps;
+    a.gn_groups = d->gn_groups; a.gn_act = d->gn_act; a.gn_eps = d->gn_eps; a.gn_act_beta = d->gn_act_beta;
     a.gnb_raw = (const bf16*)d->gnb_raw; a.gnb_gamma = d->gnb_gamma; a.gnb_beta = d->gnb_beta; a.gnb_stats = d->gnb_stats;
     a.gnb_part = d->gnb_part; a.gnb_draw = (bf16*)d->gnb_draw; a.gnb_groups = d->gnb_groups; a.gnb_act = d->gnb_act;
     if (d->gnb_raw && !small_gnb_fusable(d)) return 0;          // another kernel may take it (or the caller gets the error there)

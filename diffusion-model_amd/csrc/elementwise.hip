@@ -34,7 +34,7 @@ int ddpm_check_launch(const char* what) {
 }
 
 extern "C" const char* ddpm_last_error(void) { return g_err; }
-extern "C" int ddpm_abi_version(void) { return 3; }
+extern "C" int ddpm_abi_version(void) { return 4; }
 
 // Reproducible sums (no counterpart in the reference, which leaves torch's own choice of reduction order alone): when on,
 // every launcher whose kernel combines per-workgroup partial sums with atomics runs that kernel as ONE workgroup, so the sum is

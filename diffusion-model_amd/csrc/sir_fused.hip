@@ -31,6 +31,7 @@ struct SirArgs {
     bf16* raw_o; float* st3;
     int N, act;
     float eps;
+    const float* ab1; const float* ab2;      // swish / hardswish: the two activation modules' learnable scalars (else null)
 };
 
 // Diagnostic build only (-DSIR_STAMPS): lane 0 of every wave records the shader clock at phase boundaries into a
@@ -236,7 +237,8 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         __syncthreads();
     };
     // normalise + activation + dropout of xr[] -> LDS tile (in place) and optionally global memory
-    auto apply_phase = [&](const float* gamma, const float* beta, bool mask, const unsigned (&mk)[E1::NV], bf16* y_out) {
+    auto apply_phase = [&](const float* gamma, const float* beta, bool mask, const unsigned (&mk)[E1::NV], bf16* y_out, const float* ab) {
+        const float bsc = ACT_HAS_BETA(ACT) ? *ab : 1.f;
         float ga[8], be[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ga[j] = gamma[v1 * 8 + j]; be[j] = beta[v1 * 8 + j]; }
@@ -252,7 +254,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
                 const int g = (v1 * 8 + j) / E1::CPG;
                 const float mean = s_mr[(img * SIR_G + g) * 2], rstd = s_mr[(img * SIR_G + g) * 2 + 1];
                 const float sc = ga[j] * rstd, sh = be[j] - mean * sc;
-                float z = act_c<ACT>((float)xr[k][j] * sc + sh);
+                float z = act_c<ACT>((float)xr[k][j] * sc + sh, bsc);
                 if (mask) z = (m >> j) & 1 ? z * a.mscale : 0.f;
                 o[j] = (bf16)z;
             }
@@ -265,7 +267,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
     for (int k = 0; k < E1::NV; ++k) xr[k] = *(const bf16x8*)(s_e + (r1 + k * E1::RPP) * ES + v1 * 16);
     stats_phase(rec ? a.raw_e : nullptr, rec ? a.st1 : nullptr);
     SIR_STAMP(3);
-    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e != nullptr, mk_e, rec ? a.y_e : nullptr);
+    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e != nullptr, mk_e, rec ? a.y_e : nullptr, a.ab1);
     __syncthreads();
     SIR_STAMP(4);
 
@@ -307,7 +309,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
     if (wave < MT * (C / 32)) gemm_prefetch<E>(bfrag2, a.wp + (long long)((wave / MT) * 32 + (lane & 31)) * E, lane);
     stats_phase(rec ? a.raw_d : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
     SIR_STAMP(6);
-    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e != nullptr, mk_d, rec ? a.y_d : nullptr);
+    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e != nullptr, mk_d, rec ? a.y_d : nullptr, a.ab2);
     __syncthreads();
     SIR_STAMP(7);
 
@@ -401,6 +403,8 @@ __global__ __launch_bounds__(SIR_THREADS, sir_fwd_waves(C, W)) void sir_fwd_kern
     switch (a.act) {
         case ACT_GELU: sir_fwd_body<C, W, ACT_GELU>(a, smem); break;
         case ACT_SILU: sir_fwd_body<C, W, ACT_SILU>(a, smem); break;
+        case ACT_SWISH: sir_fwd_body<C, W, ACT_SWISH>(a, smem); break;
+        case ACT_HARDSWISH: sir_fwd_body<C, W, ACT_HARDSWISH>(a, smem); break;
         default: sir_fwd_body<C, W, ACT_RELU>(a, smem); break;
     }
 }
@@ -510,7 +514,8 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
         group_finish<E, M, HW, 1>(tid, s_part, s_mr, a.eps, st_out, n0, a.N);
         __syncthreads();
     };
-    auto apply_phase = [&](const float* gamma, const float* beta, const unsigned char* mask, bf16* y_out) {
+    auto apply_phase = [&](const float* gamma, const float* beta, const unsigned char* mask, bf16* y_out, const float* ab) {
+        const float bsc = ACT_HAS_BETA(ACT) ? *ab : 1.f;
         float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -527,7 +532,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float z = act_c<ACT>((float)xr[k][j] * sc[j] + sh[j]);
+                float z = act_c<ACT>((float)xr[k][j] * sc[j] + sh[j], bsc);
                 if (mask) z = (mk[k] >> j) & 1 ? z * a.mscale : 0.f;
                 o[j] = (bf16)z;
             }
@@ -540,7 +545,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) xr[k] = *(const bf16x8*)(s_e + (r1 + k * E1::RPP) * ES + v1 * 16);
     stats_phase(rec ? raw_eb : nullptr, rec ? a.st1 : nullptr);
-    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e ? m_eb : nullptr, rec ? y_eb : nullptr);
+    apply_phase(s_p + P_G1, s_p + P_B1, a.m_e ? m_eb : nullptr, rec ? y_eb : nullptr, a.ab1);
     __syncthreads();
 
     // ---- depthwise 3x3 from the LDS tile, four vectors at a time (accumulator registers)
@@ -589,7 +594,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
 #pragma unroll
     for (int ks = 0; ks < E / 16; ++ks) bf2[ks] = *(const bf16x8*)(a.wp + (long long)(lane & 31) * E + ks * 16 + (lane >> 5) * 8);
     stats_phase(rec ? raw_db : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
-    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e ? m_db : nullptr, rec ? y_db : nullptr);
+    apply_phase(s_p + P_G2, s_p + P_B2, a.m_e ? m_db : nullptr, rec ? y_db : nullptr, a.ab2);
     __syncthreads();
 
     // ---- project: all of this wave's tiles stay in accumulators until every wave has read the expanded tile
@@ -665,6 +670,8 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_fwd_big_kernel(const SirArgs 
     switch (a.act) {
         case ACT_GELU: sir_fwd_big_body<C, W, ACT_GELU>(a, smem); break;
         case ACT_SILU: sir_fwd_big_body<C, W, ACT_SILU>(a, smem); break;
+        case ACT_SWISH: sir_fwd_big_body<C, W, ACT_SWISH>(a, smem); break;
+        case ACT_HARDSWISH: sir_fwd_big_body<C, W, ACT_HARDSWISH>(a, smem); break;
         default: sir_fwd_big_body<C, W, ACT_RELU>(a, smem); break;
     }
 }
@@ -720,14 +727,15 @@ static int sir_launch(const SirArgs& a, hipStream_t stream) {
 
 extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act) {
     if (H != W || E != 2 * C || groups != SIR_G) return 0;
-    if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU) return 0;
+    if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU && !ACT_HAS_BETA(act)) return 0;
     return (C == 32 && W == 16) || (C == 64 && W == 8) || (C == 128 && W == 4) || (C == 256 && W == 2) ||
            (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16);
 }
 
-// 1 when the backward kernel (ddpm_sir_backward) also covers the shape
+// 1 when the backward kernel (ddpm_sir_backward) also covers the shape.  swish / hardswish: forward only (their scalar's
+// gradient comes from the per-unit GroupNorm backward, which runs on what the fused forward saved).
 extern "C" int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act) {
-    return ddpm_sir_supported(C, H, W, E, groups, act);
+    return !ACT_HAS_BETA(act) && ddpm_sir_supported(C, H, W, E, groups, act);
 }
 
 extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
@@ -738,6 +746,7 @@ extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
     DDPM_REQUIRE(ddpm_sir_supported(d->C, d->H, d->W, d->E, d->groups, d->act),
                  "sir_forward: unsupported shape C=%d %dx%d E=%d groups=%d act=%d (use the unfused kernels)", d->C, d->H, d->W, d->E,
                  d->groups, d->act);
+    DDPM_REQUIRE(!ACT_HAS_BETA(d->act) || (d->act_b1 && d->act_b2), "sir_forward: swish / hardswish need the two activation modules' scalars (act_b1, act_b2)");
     const bool rec = d->raw_e != nullptr;
     if (rec) DDPM_REQUIRE(d->y_e && d->st1 && d->raw_d && d->y_d && d->st2 && d->raw_o && d->st3, "sir_forward: incomplete set of saved-tensor pointers");
     SirArgs a;
@@ -750,6 +759,7 @@ extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
     a.raw_d = (bf16*)d->raw_d; a.y_d = (bf16*)d->y_d; a.st2 = d->st2;
     a.raw_o = (bf16*)d->raw_o; a.st3 = d->st3;
     a.N = d->N; a.act = d->act; a.eps = d->eps;
+    a.ab1 = d->act_b1; a.ab2 = d->act_b2;
     if (d->C == 32 && d->W == 32) return sir_big_launch<32, 32>(a, stream);
     if (d->C == 32 && d->W == 16) return sir_launch<32, 16>(a, stream);
     if (d->C == 64 && d->W == 8) return sir_launch<64, 8>(a, stream);

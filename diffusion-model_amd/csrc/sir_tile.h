@@ -20,6 +20,14 @@ __device__ __forceinline__ float act_c(float z) {
     else if constexpr (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
     else return z;
 }
+// the same with the learnable scalar b of swish / hardswish (neural_nets/activations.py:25-63 of the reference); the other
+// codes ignore it
+template <int ACT>
+__device__ __forceinline__ float act_c(float z, float b) {
+    if constexpr (ACT == ACT_SWISH) return z * sigmoid_fast(b * z);
+    else if constexpr (ACT == ACT_HARDSWISH) return z * hardsigmoid_of(b * z);
+    else return act_c<ACT>(z);
+}
 
 // Shape bookkeeping of one elementwise phase over an [M][CH] bf16 tile: thread -> (row, 8-channel vector).
 template <int CH, int M>

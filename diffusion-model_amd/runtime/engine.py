@@ -421,7 +421,8 @@ class UNetEngine:
             bias = P[name + ".bias"]
             cout = bias.shape[0]
             site = act_site(norm or name)
-            bsc = act_scalar(site, act)           # swish / hardswish: applied by the GroupNorm/activation kernels only
+            bsc = act_scalar(site, act)           # swish / hardswish: in the GroupNorm epilogues (fused or per-unit), not in the bare
+                                                  # convolution epilogues
             if bsc is None and norm is None and tape is None and res is None and out_mask is None:
                 # inference, no normalisation: the activation runs in the convolution's epilogue (no pre-activation is kept)
                 return Var(ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
@@ -433,12 +434,13 @@ class UNetEngine:
             # plus a GroupNorm launch beats the whole-image kernels that finish the GroupNorm themselves (those are sized
             # for the latency-bound small batches)
             wide = ops.conv_pipe_wins(kind, x0.v, None if x1 is None else x1.v, cout) and in_mask is None and out_mask is None
-            if (not wide and in_affine is None and bsc is None and norm and in_mask is None and out_mask is None
+            if (not wide and in_affine is None and norm and in_mask is None and out_mask is None
                     and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups)):
                 # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
+                # (swish / hardswish included: the epilogue reads the module's scalar)
                 raw, y, stats = ops.conv_forward(kind, x0.v, wf, bias, cout, x1=None if x1 is None else x1.v,
                                                  in_add=None if in_add is None else in_add.v,
-                                                 gn=(gamma, beta, groups, act, None if res is None else res.v), keep_raw=tape is not None)
+                                                 gn=(gamma, beta, groups, act, None if res is None else res.v, bsc), keep_raw=tape is not None)
             elif bsc is None and norm is None and res is None and out_mask is None and cout % 8 == 0 and x0.v.shape[1] > 4:
                 # no normalisation: the activated tensor is a second result of the convolution's launch (the pre-activation
                 # stays for the backward pass)
@@ -652,7 +654,8 @@ class UNetEngine:
                 y, sv = ops.sir_forward(xin.v, wc.fwd[ne], P[ne + ".bias"], P[g1 + ".weight"], P[g1 + ".bias"], wc.dw[nd], P[nd + ".bias"],
                                         P[g2 + ".weight"], P[g2 + ".bias"], wc.fwd[npj], P[npj + ".bias"], P[g3 + ".weight"],
                                         P[g3 + ".bias"], sp.groups, sp.act, masks=(m_in, m_e, m_d), mask_scale=mscale,
-                                        record=tape is not None)
+                                        record=tape is not None,
+                                        act_betas=(act_scalar(act_site(g1), sp.act), act_scalar(act_site(g2), sp.act)))
                 out = Var(y)
                 if tape is not None and not ops.sir_backward_supported(cc, hh, ww, ech, sp.groups, sp.act):
                     # forward fused, backward through the per-unit kernels (they read what the fused forward saved)

@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("gn_groups", _i), ("gn_act", _i), ("gn_eps", _f), ("out2", _vp), ("act2", _i),
         ("gnb_raw", _vp), ("gnb_gamma", _vp), ("gnb_beta", _vp), ("gnb_stats", _vp), ("gnb_part", _vp), ("gnb_draw", _vp),
         ("gnb_groups", _i), ("gnb_act", _i), ("C0_used", _i), ("gn_part", _vp), ("gn_part_groups", _i), ("in_affine", _vp), ("in_affine_act", _i),
+        ("gn_act_beta", _vp),
     ]
 
 
@@ -52,7 +53,7 @@ class GnDesc(C.Structure):
 class SirDesc(C.Structure):
     _fields_ = [(k, _vp) for k in ("x", "y", "we", "be", "g1", "b1", "wd", "bd", "g2", "b2", "wp", "bp", "g3", "b3", "m_in", "m_e", "m_d")] + [
         ("mask_scale", _f), ("eps", _f)] + [(k, _vp) for k in ("raw_e", "y_e", "st1", "raw_d", "y_d", "st2", "raw_o", "st3")] + [
-        (k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act", "pad")]
+        (k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act", "pad")] + [("act_b1", _vp), ("act_b2", _vp)]
 
 
 class SirBwdDesc(C.Structure):

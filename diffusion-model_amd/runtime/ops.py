@@ -59,7 +59,7 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
     the GroupNorm/activation backward runs in the loader (where conv_gnb_fusable says so), filling part [N][3][C] and draw.
     act2: also return act2(result) as a second tensor (the result itself without activation): returns (raw, y).
     c0_used: promise that only the first c0_used (1..4) channels of x0 are non-zero (zero-padded image tensors).
-    gn = (gamma, beta, groups, act, res or None): GroupNorm + activation (+ residual) finished in the same launch (only
+    gn = (gamma, beta, groups, act, res or None[, the scalar of swish / hardswish]): GroupNorm + activation (+ residual) finished in the same launch (only
     where conv_gn_fusable says so); returns (raw, y, stats) instead of the raw result alone; keep_raw=False (inference): the raw
     result is not stored and comes back as None.
     gn_part_groups > 0: returns (raw, part) with part = fp32 [N][groups][tiles][2] per-tile sums (x, x^2) of the result for
@@ -106,7 +106,8 @@ def conv_forward(kind: int, x0: Tensor, w: Tensor, bias: Optional[Tensor], cout:
         y = torch.empty_like(out)
         d.out2, d.act2 = hip.ptr(y), act2
     if gn is not None:
-        gamma, beta, groups, gact, gres = gn
+        gamma, beta, groups, gact, gres = gn[:5]
+        d.gn_act_beta = _scalar_ptr(gact, gn[5] if len(gn) > 5 else None)
         y = torch.empty(n, oh, ow, cout, device=x0.device, dtype=BF16)
         stats = torch.empty(n, groups, 2, device=x0.device, dtype=torch.float32)
         d.gn_gamma, d.gn_beta, d.gn_out, d.gn_stats, d.gn_res = hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(stats), hip.ptr(gres)
@@ -402,8 +403,9 @@ def sir_backward_supported(c: int, h: int, w: int, e: int, groups: int, act: int
 
 def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: Tensor, bd: Tensor, g2: Tensor, b2: Tensor,
                 wp: Tensor, bp: Tensor, g3: Tensor, b3: Tensor, groups: int, act: int, *, masks=(None, None, None),
-                mask_scale: float = 1.0, record: bool = False, eps: float = 1e-5):
+                mask_scale: float = 1.0, record: bool = False, eps: float = 1e-5, act_betas=(None, None)):
     """One fused SeparableInvertResidual block.  x: NHWC bf16 [N,H,W,C]; we: bf16 [1][E][C]; wd: fp32 [9][E]; wp: bf16 [1][C][E].
+    act_betas: swish / hardswish, the learnable scalars of the block's two activation modules (one-element fp32 device tensors).
     Returns (y, saved) where saved is None or the dict of tensors the backward pass needs
     (raw_e, y_e, st1, raw_d, y_d, st2, raw_o, st3)."""
     n, h, w, c = x.shape
@@ -422,7 +424,8 @@ def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: T
                     m_in=hip.ptr(masks[0]), m_e=hip.ptr(masks[1]), m_d=hip.ptr(masks[2]), mask_scale=mask_scale, eps=eps,
                     raw_e=hip.ptr(sv.get("raw_e")), y_e=hip.ptr(sv.get("y_e")), st1=hip.ptr(sv.get("st1")),
                     raw_d=hip.ptr(sv.get("raw_d")), y_d=hip.ptr(sv.get("y_d")), st2=hip.ptr(sv.get("st2")),
-                    raw_o=hip.ptr(sv.get("raw_o")), st3=hip.ptr(sv.get("st3")), N=n, C=c, H=h, W=w, E=e, groups=groups, act=act, pad=0)
+                    raw_o=hip.ptr(sv.get("raw_o")), st3=hip.ptr(sv.get("st3")), N=n, C=c, H=h, W=w, E=e, groups=groups, act=act, pad=0,
+                    act_b1=_scalar_ptr(act, act_betas[0]), act_b2=_scalar_ptr(act, act_betas[1]))
 
     def cost():
         nb = _nb(x, y, we, wp, wd) + sum(_nb(t) for t in sv.values()) + sum(_nb(m) for m in masks)

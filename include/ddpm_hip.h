@@ -180,6 +180,9 @@ typedef struct ddpm_conv_desc {
                                 * channel from ddpm_gn_fold_affine; the loader computes act(x * scale + shift), rounded to bf16 as
                                 * the GroupNorm launch would have stored it.  One input tensor, no in_add; in_mask applies after. */
     int in_affine_act;         /* DDPM_ACT none / gelu / silu */
+    const float* gn_act_beta;  /* the fused GroupNorm's activation is swish / hardswish (neural_nets/activations.py:25-63): device
+                                * pointer to its learnable scalar; forward only (the backward of such a unit runs on
+                                * ddpm_gn_act_backward, which also produces the scalar's gradient) */
 } ddpm_conv_desc;
 int ddpm_conv_gn_fusable(const ddpm_conv_desc* d);
 int ddpm_conv_gnb_fusable(const ddpm_conv_desc* d);
@@ -402,6 +405,10 @@ typedef struct ddpm_sir_desc {
     void* raw_d; void* y_d; float* st2;
     void* raw_o; float* st3;
     int32_t N, C, H, W, E, groups, act, pad;
+    const float* act_b1; const float* act_b2;   /* act = swish / hardswish: device pointers to the learnable scalars of the block's two
+                                                 * activation modules (expansion.3, depthwise.3: conv_block.py:66-76,89-96); the fused
+                                                 * BACKWARD does not take these activations (ddpm_sir_backward_supported = 0): the
+                                                 * per-unit kernels run it from what this launch saved */
 } ddpm_sir_desc;
 int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act);
 int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act);   /* shapes ddpm_sir_backward accepts */

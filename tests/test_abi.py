@@ -28,7 +28,7 @@ def test_header_symbols_exported():
 def test_binding_covers_header():
     names = set(declared_functions()) - {"ddpm_last_error"}
     assert names == set(hip._PROTOS), (names ^ set(hip._PROTOS))
-    assert hip.lib().ddpm_abi_version() == 3
+    assert hip.lib().ddpm_abi_version() == 4
 
 
 def test_invalid_arguments_are_reported_without_a_gpu():

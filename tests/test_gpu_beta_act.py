@@ -67,17 +67,77 @@ def test_groupnorm_with_learnable_scalar_activation(dev, act, n, c, h, g):
 
 
 @pytest.mark.parametrize("act", ACTS)
-def test_fused_launches_decline_the_scalar_activations(dev, act):
-    """the convolution epilogues, the bare-activation backward and the single-launch inverted-residual / embedding kernels
-    have no scalar input: they refuse these codes instead of computing silu / hardswish with an implicit scalar of 1"""
+def test_scalar_activations_in_the_fused_launches(dev, act):
+    """The single-launch inverted-residual FORWARD and the convolution launches that finish their GroupNorm take these codes
+    together with the modules' scalars; launches without a scalar input (bare convolution epilogues, the bare-activation
+    backward) and the single-launch inverted-residual backward refuse them instead of computing silu / hardswish with an
+    implicit scalar of 1."""
     code = hip.ACT[act]
-    assert not ops.sir_supported(32, 8, 8, 64, 16, code)
+    assert ops.sir_supported(32, 16, 16, 64, 16, code)
+    assert not ops.sir_backward_supported(32, 16, 16, 64, 16, code)
     x = torch.zeros(2, 8, 8, 32, device=dev, dtype=torch.bfloat16)
     w = torch.zeros(1, 32, 32, device=dev, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="swish"):
         ops.conv_forward(hip.CONV_1X1, x, w, None, 32, act=code)
     with pytest.raises(RuntimeError, match="swish"):
         ops.act_backward(x, x, code, torch.zeros(2 * 32, device=dev), 1)
+    w3 = torch.zeros(9, 32, 32, device=dev, dtype=torch.bfloat16)
+    ones, zeros = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    with pytest.raises(ValueError, match="scalar"):          # a fused GroupNorm with one of these codes and no scalar
+        ops.conv_forward(hip.CONV_3X3_S1, x, w3, zeros, 32, gn=(ones, zeros, 16, code, None))
+
+
+class _Names:
+    """launch probe: records the kernel family of every launch"""
+    def __init__(self):
+        self.names = []
+
+    def launch(self, kernel, cost, fn):
+        fn()
+        self.names.append(kernel() if callable(kernel) else kernel)     # (a convolution names its kernel after the launch)
+
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("c,h", [(32, 16), (64, 8), (32, 32), (256, 2)])
+def test_fused_inverted_residual_forward_with_scalar_activations(dev, act, c, h):
+    """swish / hardswish (scalars 0.7 and 1.6, away from the initial 1) through the one-launch block forward against the same
+    block on the per-unit kernels: output within one bf16 step of its scale, in eval mode and in training mode (where the
+    per-unit backward then runs on what the fused forward saved: gradients of the input, of a weight and of both scalars
+    against the all-per-unit pass)."""
+    blk = SeparableInvertResidual(c, c, activation=act, **KW).to(dev)
+    sd = blk.state_dict()
+    sd["expansion.3.beta"] = torch.tensor(0.7)
+    sd["depthwise.3.beta"] = torch.tensor(1.6)
+    blk.load_state_dict(sd)
+    x = (hash_normal((3, c, h, h), 71) * 1.2).to(dev)
+    gy = hash_normal((3, c, h, h), 72).to(dev)
+
+    def run(fused: bool, train: bool):
+        blk.train(train)
+        blk.zero_grad(set_to_none=True)
+        eng = blk._get_engine()
+        eng.fuse_sir = fused
+        rec = _Names()
+        ops.PROBE = rec
+        try:
+            xin = x.clone().requires_grad_(train)
+            y = blk(xin)
+            if train:
+                y.backward(gy)
+        finally:
+            ops.PROBE = None
+        grads = (xin.grad, blk.get_parameter("projection.1.weight").grad, blk.get_parameter("expansion.3.beta").grad,
+                 blk.get_parameter("depthwise.3.beta").grad) if train else ()
+        return y.detach().float(), [g.detach().float().clone() for g in grads], rec.names
+
+    for train in (False, True):
+        y1, g1, names1 = run(True, train)
+        y0, g0, names0 = run(False, train)
+        assert any(k.startswith("sir_fwd") for k in names1) and not any(k.startswith("sir_fwd") for k in names0), (names1, names0)
+        assert not any(k.startswith("sir_bwd") for k in names1)
+        assert (y1 - y0).abs().max().item() <= 1.6e-2 * y0.abs().max().item()
+        for a, b in zip(g1, g0):
+            assert l2(a.cpu(), b.cpu()) < 0.05, l2(a.cpu(), b.cpu())
 
 
 @pytest.mark.parametrize("act", ACTS)
