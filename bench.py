@@ -31,10 +31,10 @@ YAML = dict(stages_channels=[32, 64, 128, 256], expand_factor=2, drop_p=0.1, T=1
             base_groups_norm=4, initializer="he_normal", dtype=None)
 
 
-def build_model(dev, channels, attention_stages=()):
+def build_model(dev, channels, attention_stages=(), activation=None):
     torch.manual_seed(42 + int(os.environ.get("RANK", 0)))
     extra = {"attention_stages": list(attention_stages)} if attention_stages else {}
-    m = dm_ddpm.DDPM(dm_unets.BaseUNet, **YAML, is_conditional=False, img_channels=channels, reconstruction_method="mse",
+    m = dm_ddpm.DDPM(dm_unets.BaseUNet, **{**YAML, "activation": activation or YAML["activation"]}, is_conditional=False, img_channels=channels, reconstruction_method="mse",
                      latent_dim=512, device=dev, **extra)
     return m.to(dev)
 
@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--sample-batch", type=int, default=1024, help="images per GPU per sampling job (BASELINE configs[3] samples 1024 images)")
     ap.add_argument("--sample-streams", type=int, default=2, help="chains of sample-batch/streams images advanced on this many streams")
     ap.add_argument("--attention-stages", default="", help="comma-separated stages that carry a self-attention ConditionalModule (other configs)")
+    ap.add_argument("--activation", default="gelu", help="the network's activation (the reference's training config uses gelu; its block default is swish)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam(capturable) instead of the fused flat Adam")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after backward instead of the overlapped two-phase exchange")
@@ -325,7 +326,7 @@ def main():
         else:
             td.init_process_group("nccl", device_id=dev)
 
-    m = build_model(dev, a.channels, [int(v) for v in a.attention_stages.split(",") if v.strip()])
+    m = build_model(dev, a.channels, [int(v) for v in a.attention_stages.split(",") if v.strip()], a.activation)
     m.train()
     crit = ELBOLoss("mse")
     opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=0) if not a.torch_adam else torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
@@ -375,7 +376,8 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"DDPM train step, {a.size}x{a.size}x{a.channels}{shaped}, batch {a.batch}/GPU, "
                                f"stages [32,64,128,256], T=120, drop_p=0.1, Adam (lr 1e-3), gradient_accumulation_steps=1"
-                               + (f", self-attention at stages {a.attention_stages}" if a.attention_stages else ""),
+                               + (f", self-attention at stages {a.attention_stages}" if a.attention_stages else "")
+                               + (f", activation {a.activation}" if a.activation != "gelu" else ""),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph,
                    "grad_exchange": ("none" if not dist else "one all-reduce after backward" if a.no_overlap else
                                      "flat ranges of one gradient buffer: decoder half after the 2nd of 4 backward phases, the encoder's deep stages + latent after the 3rd, the small rest at the end; all but the last travel during the backward pass"),

@@ -185,6 +185,7 @@ class UNetEngine:
         self._pin_captured: List[Tensor] = []
         self.fuse_sir = True            # one launch per inverted-residual block where the fused kernel supports the shape
         self.conv_stats = os.environ.get("DDPM_CONV_STATS", "1") != "0"   # large images: GroupNorm sums from the convolution's tiles
+        self.fuse_scalar_act = os.environ.get("DDPM_FUSE_SCALAR_ACT", "1") != "0"   # swish / hardswish in the fused forward launches (A/B switch)
         self.dw_on_load = os.environ.get("DDPM_DW_ON_LOAD", "1") != "0"      # inference, large images: the expansion's GroupNorm + act in the depthwise loader
         self.norm_on_load = os.environ.get("DDPM_NORM_ON_LOAD", "1") != "0"  # inference, large images: GroupNorm + act in the consumer's loader
         # inference: the low-resolution stages as up to three launches with the activations resident in LDS (csrc/unet_lds.hip).
@@ -434,7 +435,7 @@ class UNetEngine:
             # plus a GroupNorm launch beats the whole-image kernels that finish the GroupNorm themselves (those are sized
             # for the latency-bound small batches)
             wide = ops.conv_pipe_wins(kind, x0.v, None if x1 is None else x1.v, cout) and in_mask is None and out_mask is None
-            if (not wide and in_affine is None and norm and in_mask is None and out_mask is None
+            if (not wide and in_affine is None and (bsc is None or self.fuse_scalar_act) and norm and in_mask is None and out_mask is None
                     and ops.conv_gn_fusable(kind, x0.v, None if x1 is None else x1.v, cout, groups)):
                 # low-resolution stages: a workgroup holds whole images and groups, the normalisation ends in the same launch
                 # (swish / hardswish included: the epilogue reads the module's scalar)
@@ -648,7 +649,8 @@ class UNetEngine:
                 e = conv_unit(pre + "expansion.1", xin, in_mask=m_in, norm=pre + "expansion.2", groups=sp.groups, act=sp.act, out_mask=m_e)
                 d = dw_unit(pre, e, m_d, stride)
                 return conv_unit(pre + "projection.1", d, norm=pre + "projection.2", groups=sp.groups, act=0)
-            if self.fuse_sir and ops.sir_supported(cc, hh, ww, ech, sp.groups, sp.act):
+            if (self.fuse_sir and ops.sir_supported(cc, hh, ww, ech, sp.groups, sp.act)
+                    and (self.fuse_scalar_act or sp.act not in hip.ACT_WITH_SCALAR)):
                 # whole block in one launch (activations resident in LDS); training saves what the per-unit backward needs
                 g1, g2, g3 = pre + "expansion.2", pre + "depthwise.2", pre + "projection.2"
                 y, sv = ops.sir_forward(xin.v, wc.fwd[ne], P[ne + ".bias"], P[g1 + ".weight"], P[g1 + ".bias"], wc.dw[nd], P[nd + ".bias"],
