@@ -732,10 +732,10 @@ extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int ac
            (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16);
 }
 
-// 1 when the backward kernel (ddpm_sir_backward) also covers the shape.  swish / hardswish: forward only (their scalar's
-// gradient comes from the per-unit GroupNorm backward, which runs on what the fused forward saved).
+// 1 when the backward kernel (ddpm_sir_backward) also covers the shape
 extern "C" int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act) {
-    return !ACT_HAS_BETA(act) && ddpm_sir_supported(C, H, W, E, groups, act);
+    if (ACT_HAS_BETA(act) && !sir_bwd_takes_scalar_acts(C, W)) return 0;
+    return ddpm_sir_supported(C, H, W, E, groups, act);
 }
 
 extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {

@@ -45,6 +45,8 @@ struct SirBwdArgs {
     float* part1; float* part2; float* part3;      // [N][3][E], [N][3][E], [N][3][C]: d gamma, d beta, column sum of the raw gradient
     float* dwpart;                                 // [workgroups][10][E]: nine tap gradients, then the depthwise bias gradient
     int N, act;
+    const float* ab1; const float* ab2;            // swish / hardswish: the two activation modules' learnable scalars ...
+    float* dbp1; float* dbp2;                      // ... and [workgroups][waves] partial sums of their gradients
 };
 
 template <int ACT>
@@ -53,6 +55,27 @@ __device__ __forceinline__ float act_d(float z) {
     else if constexpr (ACT == ACT_SILU) { const float s = sigmoid_fast(z); return s * (1.0f + z * (1.0f - s)); }
     else if constexpr (ACT == ACT_RELU) return z > 0.f ? 1.f : 0.f;
     else return 1.f;
+}
+
+// The same for the codes with a learnable scalar b (swish: z sigmoid(b z), hardswish: z hardsigmoid(b z)), together with the
+// derivative with respect to b; the other codes ignore b and return db = 0.
+template <int ACT>
+__device__ __forceinline__ float act_d_db(float z, float b, float& db) {
+    if constexpr (ACT == ACT_SWISH) {
+        const float s = sigmoid_fast(b * z), t = s * (1.0f - s);
+        db = z * z * t;
+        return s + b * z * t;
+    } else if constexpr (ACT == ACT_HARDSWISH) {
+        // 1/6 inside |u| < 3, else 0, by arithmetic (a huge factor and a clamp to [0, 1]): compares would hold a pair of scalar
+        // registers per element until their selects run, more than the scalar file has for a tile of this size
+        const float u = b * z;
+        const float t = __builtin_amdgcn_fmed3f((3.f - fabsf(u)) * 0x1p60f, 0.f, 1.f) * (1.f / 6.f);
+        db = z * z * t;
+        return hardsigmoid_of(u) + u * t;
+    } else {
+        db = 0.f;
+        return act_d<ACT>(z);
+    }
 }
 
 // Sum r[0..7] over the R = 64 / VPR lanes of a wave that hold other rows of the same eight channels.  Every exchange
@@ -115,7 +138,10 @@ __device__ __forceinline__ float col_total(const float* s_slot, int img, int c) 
 template <int CH, int M, int HW, int IPW, int CS, int ACT>
 __device__ __forceinline__ void norm_bwd(const bf16x8 (&raw)[Ew<CH, M>::NV], float (&g)[Ew<CH, M>::NV][8], const unsigned (&mk)[Ew<CH, M>::NV],
                                          bool use_mask, float mscale, const float* gamma, const float* beta, const float* s_mr,
-                                         float* s_slot, float* s_grp, float* part, long long n0, int N, int tid) {
+                                         float* s_slot, float* s_grp, float* part, long long n0, int N, int tid,
+                                         float bsc = 1.f, float* dbp = nullptr) {
+    // bsc, dbp (swish / hardswish only): the activation's scalar, and this workgroup's [waves] slots for the partial sums of
+    // the scalar's gradient = sum of (incoming gradient) * (mask) * d act / d scalar
     using T = Ew<CH, M>;
     constexpr int NWV = SIR_THREADS / 64;
     static_assert(NWV % IPW == 0 && (M / NWV) <= HW, "a wave must not straddle images");
@@ -130,6 +156,7 @@ __device__ __forceinline__ void norm_bwd(const bf16x8 (&raw)[Ew<CH, M>::NV], flo
         mean[j] = s_mr[(img * SIR_G + grp) * 2]; rstd[j] = s_mr[(img * SIR_G + grp) * 2 + 1];
     }
     float a1[8], a2[8];
+    float dbs = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) a1[j] = a2[j] = 0.f;
 #pragma unroll
@@ -138,11 +165,23 @@ __device__ __forceinline__ void norm_bwd(const bf16x8 (&raw)[Ew<CH, M>::NV], flo
         for (int j = 0; j < 8; ++j) {
             const float xh = ((float)raw[k][j] - mean[j]) * rstd[j];
             float gg = g[k][j];
-            if constexpr (ACT != ACT_NONE) gg *= act_d<ACT>(xh * ga[j] + be[j]);
+            if constexpr (ACT_HAS_BETA(ACT)) {
+                float db;
+                const float d = act_d_db<ACT>(xh * ga[j] + be[j], bsc, db);
+                db *= gg; gg *= d;
+                if (use_mask) db = (mk[k] >> j) & 1 ? db * mscale : 0.f;
+                dbs += db;
+            } else if constexpr (ACT != ACT_NONE) {
+                gg *= act_d<ACT>(xh * ga[j] + be[j]);
+            }
             if (use_mask) gg = (mk[k] >> j) & 1 ? gg * mscale : 0.f;
             g[k][j] = gg;
             a1[j] += gg; a2[j] += gg * xh;
         }
+    }
+    if constexpr (ACT_HAS_BETA(ACT)) {
+        dbs = wave_sum(dbs);
+        if (lane == 0) dbp[wave] = dbs;
     }
     col_store<CH, M, CS>(a1, wave, vec, lane, s_slot);
     col_store<CH, M, CS>(a2, wave, vec, lane, s_slot + NWV * CS);
@@ -322,7 +361,7 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
         for (int j = 0; j < 8; ++j) g[k][j] = (float)t[j];
     }
     norm_bwd<E, M, HW, IPW, E, ACT>(rawd, g, mk_d, use_mask, a.mscale, s_p + P_G2, s_p + P_B2, s_mr + IPW * 2 * SIR_G, s_col, s_grp, a.part2,
-                                   n0, a.N, tid);
+                                   n0, a.N, tid, ACT_HAS_BETA(ACT) ? *a.ab2 : 1.f, ACT_HAS_BETA(ACT) ? a.dbp2 + blockIdx.x * NWV : nullptr);
     // the forward activation feeding the depthwise conv and the raw expansion output are needed next: request them now
     // (the widest tile has no registers to spare for the raw values during the depthwise phase: it asks for them afterwards)
     constexpr bool RAW_E_LATE = E1::NV * E >= 1024;
@@ -426,7 +465,8 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
     if constexpr (RAW_E_LATE) load_raw_e(r1b, v1b);
     bf16x8 bfrag2[GemmK<E>::KCH];
     if (wave < MT * (C / 32)) gemm_prefetch<E>(bfrag2, a.wed + (long long)((wave / MT) * 32 + (lane & 31)) * E, lane);
-    norm_bwd<E, M, HW, IPW, E, ACT>(rawe, g, mk_e, use_mask, a.mscale, s_p + P_G1, s_p + P_B1, s_mr, s_col + 0, s_grp, a.part1, n0, a.N, tid1);
+    norm_bwd<E, M, HW, IPW, E, ACT>(rawe, g, mk_e, use_mask, a.mscale, s_p + P_G1, s_p + P_B1, s_mr, s_col + 0, s_grp, a.part1, n0, a.N, tid1,
+                                   ACT_HAS_BETA(ACT) ? *a.ab1 : 1.f, ACT_HAS_BETA(ACT) ? a.dbp1 + blockIdx.x * NWV : nullptr);
 #pragma unroll
     for (int k = 0; k < E1::NV; ++k) {
         const int row = r1b * E1::NV + k;
@@ -504,11 +544,12 @@ __device__ __forceinline__ void sir_bwd_body(const SirBwdArgs& a, char* smem) {
 template <int CH, int M, int HW, int CS, int ACT>
 __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* raw_g, const unsigned char* mask_g, long long elem0, float mscale,
                                               const float* gamma, const float* beta, const float* s_mr, float* s_slot, float* s_grp,
-                                              float* part, bf16* out_g, long long n0, int tid) {
+                                              float* part, bf16* out_g, long long n0, int tid, float bsc = 1.f, float* dbp = nullptr) {
     using T = Ew<CH, M>;
     constexpr int NWV = SIR_THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
     const int vec = tid % T::VPR, r0 = tid / T::VPR;
+    float dbs = 0.f;                               // swish / hardswish: this thread's share of the scalar's gradient
     float ga[8], be[8], mean[8], rstd[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -534,7 +575,15 @@ __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* ra
             for (int j = 0; j < 8; ++j) {
                 xh[k][j] = ((float)raw[k][j] - mean[j]) * rstd[j];
                 float v = (float)gin[k][j];
-                if constexpr (ACT != ACT_NONE) v *= act_d<ACT>(xh[k][j] * ga[j] + be[j]);
+                if constexpr (ACT_HAS_BETA(ACT)) {
+                    float db;
+                    const float d = act_d_db<ACT>(xh[k][j] * ga[j] + be[j], bsc, db);
+                    db *= v; v *= d;
+                    if (mask_g) db = (mk[k] >> j) & 1 ? db * mscale : 0.f;
+                    dbs += db;
+                } else if constexpr (ACT != ACT_NONE) {
+                    v *= act_d<ACT>(xh[k][j] * ga[j] + be[j]);
+                }
                 if (mask_g) v = (mk[k] >> j) & 1 ? v * mscale : 0.f;
                 gg[k][j] = v;
             }
@@ -574,6 +623,10 @@ __device__ __forceinline__ void norm_bwd_tile(char* tile, int TS, const bf16* ra
             }
             *(bf16x8*)(tile + (r0 * T::NV + k0 + k) * TS + vec * 16) = o;
         }
+    }
+    if constexpr (ACT_HAS_BETA(ACT)) {
+        dbs = wave_sum(dbs);
+        if (lane == 0) dbp[wave] = dbs;
     }
     col_store<CH, M, CS>(a1, wave, vec, lane, s_slot);
     col_store<CH, M, CS>(a2, wave, vec, lane, s_slot + NWV * CS);
@@ -726,7 +779,8 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
 
     // ---- second GroupNorm + activation + dropout backward -> dd (in place in the tile)
     norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_d + row0 * E, use_mask ? a.m_d : nullptr, row0 * E, a.mscale, s_p + P_G2, s_p + P_B2,
-                                    s_mr + 2 * SIR_G, s_col, s_grp, a.part2, nullptr, n0, tid);
+                                    s_mr + 2 * SIR_G, s_col, s_grp, a.part2, nullptr, n0, tid, ACT_HAS_BETA(ACT) ? *a.ab2 : 1.f,
+                                    ACT_HAS_BETA(ACT) ? a.dbp2 + blockIdx.x * NWV : nullptr);
     __syncthreads();
     SIRB_STAMP(3);
     float* dwp = a.dwpart + n0 * 10 * E;
@@ -804,7 +858,8 @@ __device__ __forceinline__ void sir_bwd_big_body(const SirBwdArgs& a, char* smem
     SIRB_STAMP(5);
     // ---- first GroupNorm + activation + dropout backward -> d_e (tile + global); own elements only, no barrier needed before
     norm_bwd_tile<E, M, HW, E, ACT>(s_e, ES, a.raw_e + row0 * E, use_mask ? a.m_e : nullptr, row0 * E, a.mscale, s_p + P_G1, s_p + P_B1, s_mr,
-                                    s_col, s_grp, a.part1, a.d_e + row0 * E, n0, tid);
+                                    s_col, s_grp, a.part1, a.d_e + row0 * E, n0, tid, ACT_HAS_BETA(ACT) ? *a.ab1 : 1.f,
+                                    ACT_HAS_BETA(ACT) ? a.dbp1 + blockIdx.x * NWV : nullptr);
     __syncthreads();
     col2_flush<E, 1, E>(s_col, a.part1, n0, a.N, tid);
     SIRB_STAMP(6);
@@ -864,6 +919,8 @@ __global__ __launch_bounds__(SIR_THREADS) void sir_bwd_big_kernel(const SirBwdAr
     switch (a.act) {
         case ACT_GELU: sir_bwd_big_body<C, W, ACT_GELU>(a, smem); break;
         case ACT_SILU: sir_bwd_big_body<C, W, ACT_SILU>(a, smem); break;
+        case ACT_SWISH: sir_bwd_big_body<C, W, ACT_SWISH>(a, smem); break;
+        case ACT_HARDSWISH: sir_bwd_big_body<C, W, ACT_HARDSWISH>(a, smem); break;
         default: sir_bwd_big_body<C, W, ACT_RELU>(a, smem); break;
     }
 }
@@ -923,6 +980,16 @@ static int sir_bwd_launch(const SirBwdArgs& a, hipStream_t stream) {
     switch (a.act) {
         case ACT_GELU: return sir_bwd_launch_act<C, W, ACT_GELU>(a, stream);
         case ACT_SILU: return sir_bwd_launch_act<C, W, ACT_SILU>(a, stream);
+        case ACT_SWISH:
+        case ACT_HARDSWISH:
+            // (the two widest tiles have no registers left for the scalar's gradient: ddpm_sir_backward_supported says so and
+            // their backward runs on the per-unit kernels)
+            if constexpr (sir_bwd_takes_scalar_acts(C, W)) {
+                return a.act == ACT_SWISH ? sir_bwd_launch_act<C, W, ACT_SWISH>(a, stream) : sir_bwd_launch_act<C, W, ACT_HARDSWISH>(a, stream);
+            } else {
+                ddpm_set_error("sir_backward: swish / hardswish are not available for C=%d W=%d", C, W);
+                return DDPM_EINVAL;
+            }
         default: return sir_bwd_launch_act<C, W, ACT_RELU>(a, stream);
     }
 }
@@ -943,6 +1010,8 @@ extern "C" int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t strea
                  d->groups, d->act);
     DDPM_REQUIRE((d->m_in != nullptr) == (d->m_e != nullptr) && (d->m_e != nullptr) == (d->m_d != nullptr),
                  "sir_backward: give all three dropout masks or none");
+    DDPM_REQUIRE(!ACT_HAS_BETA(d->act) || (d->act_b1 && d->act_b2 && d->dbeta1 && d->dbeta2),
+                 "sir_backward: swish / hardswish need the two scalars (act_b1, act_b2) and the workspaces of their gradients (dbeta1, dbeta2)");
     SirBwdArgs a;
     a.dy = (const bf16*)d->dy; a.raw_e = (const bf16*)d->raw_e; a.raw_d = (const bf16*)d->raw_d; a.raw_o = (const bf16*)d->raw_o;
     a.y_e = (const bf16*)d->y_e; a.st1 = d->st1; a.st2 = d->st2; a.st3 = d->st3;
@@ -952,6 +1021,7 @@ extern "C" int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t strea
     a.dx = (bf16*)d->dx; a.d_o = (bf16*)d->d_o; a.d_e = (bf16*)d->d_e;
     a.part1 = d->part1; a.part2 = d->part2; a.part3 = d->part3; a.dwpart = d->dwpart;
     a.N = d->N; a.act = d->act;
+    a.ab1 = d->act_b1; a.ab2 = d->act_b2; a.dbp1 = d->dbeta1; a.dbp2 = d->dbeta2;
     if (d->C == 32 && d->W == 32) return sir_bwd_big_launch<32, 32>(a, stream);
     if (d->C == 32 && d->W == 16) return sir_bwd_launch<32, 16>(a, stream);
     if (d->C == 64 && d->W == 8) return sir_bwd_launch<64, 8>(a, stream);

@@ -13,6 +13,10 @@ constexpr int sir_ipw(int hw) { return hw >= 32 ? 1 : (hw == 4 ? 4 : 32 / hw); }
 // Rows the LDS tiles are allocated (and the MFMA tiles computed) for: at least one 32-row block; rows >= M are never read back.
 constexpr int sir_tile_rows(int m) { return m < 32 ? 32 : m; }
 
+// Shapes whose one-launch backward also takes swish / hardswish (it then sums the scalar's gradient as well): all but the two
+// widest tiles, which have no registers to spare for it.
+constexpr bool sir_bwd_takes_scalar_acts(int c, int w) { return !((c == 64 && w == 16) || (c == 256 && w == 4)); }
+
 template <int ACT>
 __device__ __forceinline__ float act_c(float z) {
     if constexpr (ACT == ACT_GELU) { float c, g; gelu_parts(z, c, g); return z * c; }

@@ -674,9 +674,13 @@ class UNetEngine:
                         dwbuf, off = part_alloc(nwg * 10 * ech)
                         part_entries.append((off, G.offset(nd + ".weight"), nwg, 10 * ech, 9 * ech))
                         part_entries.append((off + 9 * ech, G.offset(nd + ".bias"), nwg, 10 * ech, ech))
+                        s1, s2 = act_site(g1), act_site(g2)
+                        betas = (act_scalar(s1, sp.act), act_scalar(s2, sp.act))
+                        dbs = (None, None) if betas[0] is None else (scalar_partials(s1, nwg * 8), scalar_partials(s2, nwg * 8))
                         dx, d_o, d_e = ops.sir_backward(out.g, sv, P[g1 + ".weight"], P[g1 + ".bias"], P[g2 + ".weight"], P[g2 + ".bias"],
                                                         P[g3 + ".weight"], wc.dgrad[npj], wc.dgrad[ne], wc.dw_flip[nd], sp.groups, sp.act,
-                                                        p1, p2, p3, dwbuf, masks=(m_in, m_e, m_d), mask_scale=mscale)
+                                                        p1, p2, p3, dwbuf, masks=(m_in, m_e, m_d), mask_scale=mscale,
+                                                        act_betas=betas, dbeta_parts=dbs)
                         out.g = None
                         wgrad(K11, sv["y_d"], d_o, cc, npj)
                         wgrad(K11, xin.v, d_e, ech, ne, in_mask=m_in)

@@ -59,7 +59,8 @@ class SirDesc(C.Structure):
 class SirBwdDesc(C.Structure):
     _fields_ = [(k, _vp) for k in ("dy", "raw_e", "raw_d", "raw_o", "y_e", "st1", "st2", "st3", "g1", "b1", "g2", "b2", "g3", "wpd", "wed",
                                    "wdf", "m_in", "m_e", "m_d", "dx", "d_o", "d_e", "part1", "part2", "part3", "dwpart")] + [
-        ("mask_scale", _f)] + [(k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act")]
+        ("mask_scale", _f)] + [(k, C.c_int32) for k in ("N", "C", "H", "W", "E", "groups", "act")] + [
+        (k, _vp) for k in ("act_b1", "act_b2", "dbeta1", "dbeta2")]
 
 
 EMBED_MAX = 8

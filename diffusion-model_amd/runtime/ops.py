@@ -441,9 +441,11 @@ def sir_workgroups(hw: int, n: int) -> int:
 
 def sir_backward(dy: Tensor, saved: dict, g1: Tensor, b1: Tensor, g2: Tensor, b2: Tensor, g3: Tensor, wpd: Tensor, wed: Tensor,
                  wdf: Tensor, groups: int, act: int, part1: Tensor, part2: Tensor, part3: Tensor, dwpart: Tensor, *,
-                 masks=(None, None, None), mask_scale: float = 1.0):
+                 masks=(None, None, None), mask_scale: float = 1.0, act_betas=(None, None), dbeta_parts=(None, None)):
     """Data-gradient chain of one fused block.  saved: what sir_forward(record=True) returned.  wpd: bf16 [1][E][C],
-    wed: bf16 [1][C][E] (data-gradient weight copies), wdf: fp32 [9][E] flipped taps.  Returns (dx, d_o, d_e)."""
+    wed: bf16 [1][C][E] (data-gradient weight copies), wdf: fp32 [9][E] flipped taps.  swish / hardswish: act_betas = the two
+    activation modules' scalars, dbeta_parts = two fp32 workspaces of sir_workgroups(h * w, n) * 8 partial sums of their
+    gradients.  Returns (dx, d_o, d_e)."""
     n, h, w, c = dy.shape
     e = wdf.shape[1]
     assert dy.dtype == BF16 and dy.is_contiguous() and wpd.shape[-2:] == (e, c) and wed.shape[-2:] == (c, e)
@@ -457,7 +459,11 @@ def sir_backward(dy: Tensor, saved: dict, g1: Tensor, b1: Tensor, g2: Tensor, b2
                        g1=hip.ptr(g1), b1=hip.ptr(b1), g2=hip.ptr(g2), b2=hip.ptr(b2), g3=hip.ptr(g3), wpd=hip.ptr(wpd), wed=hip.ptr(wed),
                        wdf=hip.ptr(wdf), m_in=hip.ptr(masks[0]), m_e=hip.ptr(masks[1]), m_d=hip.ptr(masks[2]), dx=hip.ptr(dx),
                        d_o=hip.ptr(d_o), d_e=hip.ptr(d_e), part1=hip.ptr(part1), part2=hip.ptr(part2), part3=hip.ptr(part3),
-                       dwpart=hip.ptr(dwpart), mask_scale=mask_scale, N=n, C=c, H=h, W=w, E=e, groups=groups, act=act)
+                       dwpart=hip.ptr(dwpart), mask_scale=mask_scale, N=n, C=c, H=h, W=w, E=e, groups=groups, act=act,
+                       act_b1=_scalar_ptr(act, act_betas[0]), act_b2=_scalar_ptr(act, act_betas[1]))
+    if act in hip.ACT_WITH_SCALAR:
+        assert all(p is not None and p.dtype == torch.float32 and p.numel() == sir_workgroups(h * w, n) * 8 for p in dbeta_parts)
+        d.dbeta1, d.dbeta2 = hip.ptr(dbeta_parts[0]), hip.ptr(dbeta_parts[1])
 
     def cost():
         nb = _nb(dy, dx, d_o, d_e, wpd, wed, saved["raw_e"], saved["raw_d"], saved["raw_o"], saved["y_e"]) + sum(_nb(m) for m in masks)

@@ -406,9 +406,7 @@ typedef struct ddpm_sir_desc {
     void* raw_o; float* st3;
     int32_t N, C, H, W, E, groups, act, pad;
     const float* act_b1; const float* act_b2;   /* act = swish / hardswish: device pointers to the learnable scalars of the block's two
-                                                 * activation modules (expansion.3, depthwise.3: conv_block.py:66-76,89-96); the fused
-                                                 * BACKWARD does not take these activations (ddpm_sir_backward_supported = 0): the
-                                                 * per-unit kernels run it from what this launch saved */
+                                                 * activation modules (expansion.3, depthwise.3: conv_block.py:66-76,89-96) */
 } ddpm_sir_desc;
 int ddpm_sir_supported(int C, int H, int W, int E, int groups, int act);
 int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act);   /* shapes ddpm_sir_backward accepts */
@@ -433,6 +431,9 @@ typedef struct ddpm_sir_bwd_desc {
     float* part1; float* part2; float* part3; float* dwpart;
     float mask_scale;
     int32_t N, C, H, W, E, groups, act;
+    const float* act_b1; const float* act_b2;   /* act = swish / hardswish: the two activation modules' scalars, and ... */
+    float* dbeta1; float* dbeta2;               /* ... fp32 [ddpm_sir_workgroups(H*W, N)][8] partial sums of their gradients (one per
+                                                 * wave), for the scalar fold of ddpm_reduce_rows */
 } ddpm_sir_bwd_desc;
 int ddpm_sir_workgroups(int HW, int N);
 int ddpm_sir_backward(const ddpm_sir_bwd_desc* d, ddpm_stream_t stream);

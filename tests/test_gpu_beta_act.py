@@ -68,13 +68,14 @@ def test_groupnorm_with_learnable_scalar_activation(dev, act, n, c, h, g):
 
 @pytest.mark.parametrize("act", ACTS)
 def test_scalar_activations_in_the_fused_launches(dev, act):
-    """The single-launch inverted-residual FORWARD and the convolution launches that finish their GroupNorm take these codes
-    together with the modules' scalars; launches without a scalar input (bare convolution epilogues, the bare-activation
-    backward) and the single-launch inverted-residual backward refuse them instead of computing silu / hardswish with an
-    implicit scalar of 1."""
+    """The single-launch inverted-residual forward and backward and the convolution launches that finish their GroupNorm take
+    these codes together with the modules' scalars; launches without a scalar input (bare convolution epilogues, the
+    bare-activation backward) refuse them instead of computing silu / hardswish with an implicit scalar of 1."""
     code = hip.ACT[act]
-    assert ops.sir_supported(32, 16, 16, 64, 16, code)
-    assert not ops.sir_backward_supported(32, 16, 16, 64, 16, code)
+    assert ops.sir_supported(32, 16, 16, 64, 16, code) and ops.sir_backward_supported(32, 16, 16, 64, 16, code)
+    # (the two widest tiles run these codes forward only; their backward goes through the per-unit kernels)
+    assert ops.sir_supported(64, 16, 16, 128, 16, code) and not ops.sir_backward_supported(64, 16, 16, 128, 16, code)
+    assert ops.sir_supported(256, 4, 4, 512, 16, code) and not ops.sir_backward_supported(256, 4, 4, 512, 16, code)
     x = torch.zeros(2, 8, 8, 32, device=dev, dtype=torch.bfloat16)
     w = torch.zeros(1, 32, 32, device=dev, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="swish"):
@@ -98,12 +99,12 @@ class _Names:
 
 
 @pytest.mark.parametrize("act", ACTS)
-@pytest.mark.parametrize("c,h", [(32, 16), (64, 8), (32, 32), (256, 2)])
+@pytest.mark.parametrize("c,h", [(32, 16), (64, 8), (32, 32), (256, 2), (128, 4), (64, 16)])
 def test_fused_inverted_residual_forward_with_scalar_activations(dev, act, c, h):
     """swish / hardswish (scalars 0.7 and 1.6, away from the initial 1) through the one-launch block forward against the same
-    block on the per-unit kernels: output within one bf16 step of its scale, in eval mode and in training mode (where the
-    per-unit backward then runs on what the fused forward saved: gradients of the input, of a weight and of both scalars
-    against the all-per-unit pass)."""
+    block on the per-unit kernels: output within one bf16 step of its scale, in eval mode and in training mode, where the
+    one-launch backward also produces the partial sums of both scalars' gradients: gradients of the input, of a weight and
+    of both scalars against the all-per-unit pass."""
     blk = SeparableInvertResidual(c, c, activation=act, **KW).to(dev)
     sd = blk.state_dict()
     sd["expansion.3.beta"] = torch.tensor(0.7)
@@ -115,6 +116,7 @@ def test_fused_inverted_residual_forward_with_scalar_activations(dev, act, c, h)
     def run(fused: bool, train: bool):
         blk.train(train)
         blk.zero_grad(set_to_none=True)
+        blk._engine = None                  # (a fresh engine: the backward workspace layout of a shape is laid out once per engine)
         eng = blk._get_engine()
         eng.fuse_sir = fused
         rec = _Names()
@@ -134,7 +136,8 @@ def test_fused_inverted_residual_forward_with_scalar_activations(dev, act, c, h)
         y1, g1, names1 = run(True, train)
         y0, g0, names0 = run(False, train)
         assert any(k.startswith("sir_fwd") for k in names1) and not any(k.startswith("sir_fwd") for k in names0), (names1, names0)
-        assert not any(k.startswith("sir_bwd") for k in names1)
+        fused_bwd = train and ops.sir_backward_supported(c, h, h, 2 * c, 16, hip.ACT[act])
+        assert any(k.startswith("sir_bwd") for k in names1) == fused_bwd and not any(k.startswith("sir_bwd") for k in names0)
         assert (y1 - y0).abs().max().item() <= 1.6e-2 * y0.abs().max().item()
         for a, b in zip(g1, g0):
             assert l2(a.cpu(), b.cpu()) < 0.05, l2(a.cpu(), b.cpu())
