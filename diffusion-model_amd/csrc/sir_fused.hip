@@ -729,12 +729,13 @@ extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int ac
     if (H != W || E != 2 * C || groups != SIR_G) return 0;
     if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU && !ACT_HAS_BETA(act)) return 0;
     return (C == 32 && W == 16) || (C == 64 && W == 8) || (C == 128 && W == 4) || (C == 256 && W == 2) ||
-           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16);
+           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16) || (C == 256 && W == 8);
 }
 
 // 1 when the backward kernel (ddpm_sir_backward) also covers the shape
 extern "C" int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act) {
     if (ACT_HAS_BETA(act) && !sir_bwd_takes_scalar_acts(C, W)) return 0;
+    if (C == 256 && W == 8) return 0;          // 8x8 at 256 channels (the deepest stage of 128x128 images): forward only
     return ddpm_sir_supported(C, H, W, E, groups, act);
 }
 
@@ -767,5 +768,6 @@ extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
     if (d->C == 256 && d->W == 2) return sir_launch<256, 2>(a, stream);
     if (d->C == 128 && d->W == 8) return sir_launch<128, 8>(a, stream);
     if (d->C == 64 && d->W == 16) return sir_launch<64, 16>(a, stream);
+    if (d->C == 256 && d->W == 8) return sir_launch<256, 8>(a, stream);
     return sir_launch<256, 4>(a, stream);
 }
