@@ -420,7 +420,8 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
     constexpr int E = 2 * C, HW = W * W, M = HW;
     constexpr int XS = C * 2 + 16, ES = E * 2 + 16;
     constexpr int NWV = SIR_THREADS / 64, MT = M / 32, TPW = MT / NWV;
-    static_assert(MT % NWV == 0 && C == 32, "big variant: one output-channel tile, M tiles dealt evenly");
+    constexpr int NTC = C / 32;                    // output-channel tiles of the projection
+    static_assert(MT % NWV == 0 && C % 32 == 0 && TPW * NTC <= 4, "big variant: M tiles dealt evenly, at most four accumulator tiles per wave");
     using E1 = Ew<E, M>;
     using E3 = Ew<C, M>;
     char* s_e = smem;                              // [M][ES]; later [M][XS] raw projection output
@@ -590,7 +591,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
             }
         }
     }
-    bf16x8 bf2[E / 16];                            // projection weights of this lane's output channel (one N tile)
+    bf16x8 bf2[E / 16];                            // projection weights of this lane's output channel in the first N tile
 #pragma unroll
     for (int ks = 0; ks < E / 16; ++ks) bf2[ks] = *(const bf16x8*)(a.wp + (long long)(lane & 31) * E + ks * 16 + (lane >> 5) * 8);
     stats_phase(rec ? raw_db : nullptr, rec ? a.st2 : nullptr);     // its first barrier also ends all neighbour reads
@@ -599,27 +600,38 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
 
     // ---- project: all of this wave's tiles stay in accumulators until every wave has read the expanded tile
     {
-        f32x16 acc[TPW];
+        f32x16 acc[TPW][NTC];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
+        for (int nt = 0; nt < NTC; ++nt) {
+            if (nt > 0) {                          // wider blocks: the next N tile's weights (the A fragments come from LDS again)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            const char* ap = s_e + ((wave + NWV * i) * 32 + (lane & 31)) * ES + (lane >> 5) * 16;
+                for (int ks = 0; ks < E / 16; ++ks)
+                    bf2[ks] = *(const bf16x8*)(a.wp + (long long)(nt * 32 + (lane & 31)) * E + ks * 16 + (lane >> 5) * 8);
+            }
 #pragma unroll
-            for (int ks = 0; ks < E / 16; ++ks) {
-                const bf16x8 av = *(const bf16x8*)(ap + ks * 32);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf2[ks], acc[i], 0, 0, 0);
+            for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][nt][r] = 0.f;
+                const char* ap = s_e + ((wave + NWV * i) * 32 + (lane & 31)) * ES + (lane >> 5) * 16;
+#pragma unroll
+                for (int ks = 0; ks < E / 16; ++ks) {
+                    const bf16x8 av = *(const bf16x8*)(ap + ks * 32);
+                    acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf2[ks], acc[i][nt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
-        const float b = s_p[P_BP + (lane & 31)];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
+        for (int nt = 0; nt < NTC; ++nt) {
+            const float b = s_p[P_BP + nt * 32 + (lane & 31)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wave + NWV * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                *(bf16*)(s_e + row * XS + (lane & 31) * 2) = (bf16)(acc[i][r] + b);
-            }
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave + NWV * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    *(bf16*)(s_e + row * XS + (nt * 32 + (lane & 31)) * 2) = (bf16)(acc[i][nt][r] + b);
+                }
+        }
     }
     __syncthreads();
 
@@ -729,13 +741,14 @@ extern "C" int ddpm_sir_supported(int C, int H, int W, int E, int groups, int ac
     if (H != W || E != 2 * C || groups != SIR_G) return 0;
     if (act != ACT_GELU && act != ACT_SILU && act != ACT_RELU && !ACT_HAS_BETA(act)) return 0;
     return (C == 32 && W == 16) || (C == 64 && W == 8) || (C == 128 && W == 4) || (C == 256 && W == 2) ||
-           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16) || (C == 256 && W == 8);
+           (C == 128 && W == 8) || (C == 256 && W == 4) || (C == 32 && W == 32) || (C == 64 && W == 16) || (C == 256 && W == 8) ||
+           (C == 128 && W == 16);
 }
 
 // 1 when the backward kernel (ddpm_sir_backward) also covers the shape
 extern "C" int ddpm_sir_backward_supported(int C, int H, int W, int E, int groups, int act) {
     if (ACT_HAS_BETA(act) && !sir_bwd_takes_scalar_acts(C, W)) return 0;
-    if (C == 256 && W == 8) return 0;          // 8x8 at 256 channels (the deepest stage of 128x128 images): forward only
+    if ((C == 256 && W == 8) || (C == 128 && W == 16)) return 0;    // the two deepest stages of 128x128 images: forward only
     return ddpm_sir_supported(C, H, W, E, groups, act);
 }
 
@@ -762,6 +775,7 @@ extern "C" int ddpm_sir_forward(const ddpm_sir_desc* d, ddpm_stream_t stream_) {
     a.N = d->N; a.act = d->act; a.eps = d->eps;
     a.ab1 = d->act_b1; a.ab2 = d->act_b2;
     if (d->C == 32 && d->W == 32) return sir_big_launch<32, 32>(a, stream);
+    if (d->C == 128 && d->W == 16) return sir_big_launch<128, 16>(a, stream);
     if (d->C == 32 && d->W == 16) return sir_launch<32, 16>(a, stream);
     if (d->C == 64 && d->W == 8) return sir_launch<64, 8>(a, stream);
     if (d->C == 128 && d->W == 4) return sir_launch<128, 4>(a, stream);

@@ -431,7 +431,7 @@ def sir_forward(x: Tensor, we: Tensor, be: Tensor, g1: Tensor, b1: Tensor, wd: T
         nb = _nb(x, y, we, wp, wd) + sum(_nb(t) for t in sv.values()) + sum(_nb(m) for m in masks)
         return nb, 2.0 * n * h * w * (2 * c * e + 9 * e), f"{h}x{w} C{c} E{e}" + (" rec" if record else "")
 
-    _launch("sir_fwd_big_kernel" if h * w > 256 else "sir_fwd_kernel", cost, lambda: hip.call("ddpm_sir_forward", C.byref(d), hip.stream()))
+    _launch("sir_fwd_big_kernel" if h * w * e > 256 * 256 - 1 else "sir_fwd_kernel", cost, lambda: hip.call("ddpm_sir_forward", C.byref(d), hip.stream()))
     return y, saved
 
 

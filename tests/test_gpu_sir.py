@@ -15,7 +15,7 @@ from test_gpu_layers import bits
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(2, 32, 16), (3, 64, 8), (5, 128, 4), (11, 256, 2), (2, 128, 8), (3, 256, 4), (16, 256, 2), (2, 32, 32), (3, 64, 16)]
-FWD_ONLY_SHAPES = [(3, 256, 8)]          # the deepest stage of 128x128 images: forward in one launch, backward per unit
+FWD_ONLY_SHAPES = [(3, 256, 8), (2, 128, 16)]    # the two deepest stages of 128x128 images: forward in one launch, backward per unit
 
 
 def make_params(c, e, seed):
