@@ -55,6 +55,18 @@ __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& gauss) {
     cdf = 0.5f * (1.0f + (z < 0.f ? -erf_abs : erf_abs));
 }
 
+// gelu(z) = z * Phi(z) with the same erf, rearranged for the forward pass: with e = poly * gauss (= 1 - erf|z/sqrt2|),
+// z * Phi(z) = max(z, 0) - |z| * e / 2 for either sign of z.  No sign select, no 1 - e (whose cancellation costs the negative tail
+// its relative accuracy), two instructions fewer per element than forming Phi first; the halves sit in the coefficients.
+__device__ __forceinline__ float gelu_fwd(float z) {
+    const float az = fabsf(z);
+    const float x = az * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    const float gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float half_poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+    return fmaxf(z, 0.f) - (az * gauss) * half_poly;
+}
+
 // logistic function on the fast hardware exp2 / reciprocal (1-ulp) instructions
 __device__ __forceinline__ float sigmoid_fast(float z) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
@@ -62,7 +74,7 @@ __device__ __forceinline__ float sigmoid_fast(float z) {
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
     switch (act) {
-        case ACT_GELU: { float c, g; gelu_parts(z, c, g); return z * c; }
+        case ACT_GELU: return gelu_fwd(z);
         case ACT_SILU: return z * sigmoid_fast(z);
         case ACT_RELU: return z > 0.f ? z : 0.f;
         case ACT_TANH: return tanhf(z);

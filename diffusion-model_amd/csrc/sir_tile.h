@@ -19,7 +19,7 @@ constexpr bool sir_bwd_takes_scalar_acts(int c, int w) { return !((c == 64 && w 
 
 template <int ACT>
 __device__ __forceinline__ float act_c(float z) {
-    if constexpr (ACT == ACT_GELU) { float c, g; gelu_parts(z, c, g); return z * c; }
+    if constexpr (ACT == ACT_GELU) return gelu_fwd(z);
     else if constexpr (ACT == ACT_SILU) return z * sigmoid_fast(z);
     else if constexpr (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
     else return z;

@@ -227,7 +227,7 @@ __device__ __forceinline__ void op_gn(const ddpm_lds_op& op, char* smem, int n0,
             const float sc = ga[j] * rstd, sh = be[j] - mean * sc;
             float y = (float)x[j] * sc + sh;
             if (act_on) {
-                if constexpr (ACT == ACT_GELU) { float c, gg; gelu_parts(y, c, gg); y = y * c; }
+                if constexpr (ACT == ACT_GELU) y = gelu_fwd(y);
                 else if constexpr (ACT == ACT_SILU) y = y * sigmoid_fast(y);
                 else y = y > 0.f ? y : 0.f;
             }
