@@ -47,12 +47,14 @@ int ddpm_check_launch(const char* what);
 // for every element of ~80 tensors per pass, so its instruction count matters; and since erf(z/sqrt2) needs
 // exp(-z^2/2), the Gaussian factor of GELU's derivative comes for free.
 __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& gauss) {
-    const float x = fabsf(z) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);          // v_rcp_f32 (1 ulp); an IEEE divide costs 11 instructions
-    gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);          // exp(-z^2/2) as one v_exp_f32
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * gauss;
-    cdf = 0.5f * (1.0f + (z < 0.f ? -erf_abs : erf_abs));
+    // constants folded onto |z| itself: 0.3275911 / sqrt2, sqrt(log2(e) / 2), and half of the five coefficients
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.23164189f * az);        // v_rcp_f32 (1 ulp); an IEEE divide costs 11 instructions
+    const float q = az * 0.84932180f;
+    gauss = __builtin_amdgcn_exp2f(-(q * q));                              // exp(-z^2/2) as one v_exp_f32
+    const float half_poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+    const float e2 = half_poly * gauss;                                    // (1 - erf|z/sqrt2|) / 2 = the smaller tail of Phi
+    cdf = z < 0.f ? e2 : 1.0f - e2;
 }
 
 // gelu(z) = z * Phi(z) with the same erf, rearranged for the forward pass: with e = poly * gauss (= 1 - erf|z/sqrt2|),
@@ -60,9 +62,9 @@ __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& gauss) {
 // its relative accuracy), two instructions fewer per element than forming Phi first; the halves sit in the coefficients.
 __device__ __forceinline__ float gelu_fwd(float z) {
     const float az = fabsf(z);
-    const float x = az * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
-    const float gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.23164189f * az);
+    const float q = az * 0.84932180f;
+    const float gauss = __builtin_amdgcn_exp2f(-(q * q));
     const float half_poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
     return fmaxf(z, 0.f) - (az * gauss) * half_poly;
 }

@@ -655,7 +655,9 @@ extern "C" int ddpm_check_timesteps(const int64_t* t, int64_t* safe, int n, int 
 // Column sums of an NHWC bf16 matrix [rows][cs] -> fp32 [C] (+=): the bias gradient of a convolution whose
 // output gradient is not produced by a GroupNorm backward (the image head, the time-embedding MLPs).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, long long rows, int C, int cs,
-                                                      int rows_per_block, int cvs) {
+                                                      int rows_per_block, int cvs, int fixed_order) {
+    // fixed_order (one workgroup, reproducible sums): the four waves' partial sums meet in LDS and are added in wave order
+    __shared__ float s_wave[4][64][8];
     const int cv = threadIdx.x % cvs, prow = threadIdx.x / cvs, pstep = 256 / cvs;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
@@ -677,7 +679,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
         float v = s[j];
         for (int o = 32; o >= lo; o >>= 1) v += __shfl_xor(v, o, 64);
         const int c = cv * 8 + j;
-        if (lane < lo && c < C) atomicAdd(out + c, v);
+        if (fixed_order) {
+            if (lane < lo) s_wave[threadIdx.x >> 6][lane][j] = v;
+        } else if (lane < lo && c < C) {
+            atomicAdd(out + c, v);
+        }
+    }
+    if (fixed_order) {
+        __syncthreads();
+        // cvs <= 64: wave w holds the rows (w * 64 + lane) / cvs of every pass, i.e. all four waves hold partial sums of every column
+        if (threadIdx.x < lo) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = threadIdx.x * 8 + j;
+                if (c < C) out[c] += ((s_wave[0][threadIdx.x][j] + s_wave[1][threadIdx.x][j]) + s_wave[2][threadIdx.x][j]) + s_wave[3][threadIdx.x][j];
+            }
+        }
     }
 }
 
@@ -696,7 +713,8 @@ extern "C" int ddpm_colsum(const void* x, float* out, int64_t rows, int C, int c
     DDPM_REQUIRE(rows / blocks < (1ll << 31), "colsum: too many rows for one workgroup");
     const int rpb = (int)((rows + blocks - 1) / blocks);
     blocks = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, out, (long long)rows, C, cs, rpb, cvs);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)x, out, (long long)rows, C, cs, rpb, cvs,
+                       (int)(blocks == 1 && ddpm_deterministic()));
     return ddpm_check_launch("colsum");
 }
 
