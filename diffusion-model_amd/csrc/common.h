@@ -6,6 +6,7 @@
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -216,6 +217,29 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t stream_i
     f32x4 o;
     o[0] = ra * c0; o[1] = ra * s0; o[2] = rb * c1; o[3] = rb * s1;
     return o;
+}
+
+// Sums for GroupNorm statistics straight from packed bf16 (v_dot2c_f32_bf16: both products exact, accumulated in fp32), one
+// instruction per channel pair and sum instead of unpack + add / fma per channel: s[q] += v[2q] + v[2q+1] and
+// ss[q] += v[2q]^2 + v[2q+1]^2.  Channel pairs never straddle a normalisation group where this is used (groups of 2, 4, 8 ...).
+__device__ __forceinline__ void pair_sums(const bf16x8& v, float (&s)[4], float (&ss)[4]) {
+    const bf16x2 one = {(bf16)1.f, (bf16)1.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bf16x2 p = {v[2 * q], v[2 * q + 1]};
+        s[q] = __builtin_amdgcn_fdot2_f32_bf16(p, one, s[q], false);
+        ss[q] = __builtin_amdgcn_fdot2_f32_bf16(p, p, ss[q], false);
+    }
+}
+// the same into the even entries of per-channel arrays (the odd entries stay as they are: zero)
+__device__ __forceinline__ void pair_sums(const bf16x8& v, float (&s)[8], float (&ss)[8]) {
+    const bf16x2 one = {(bf16)1.f, (bf16)1.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bf16x2 p = {v[2 * q], v[2 * q + 1]};
+        s[2 * q] = __builtin_amdgcn_fdot2_f32_bf16(p, one, s[2 * q], false);
+        ss[2 * q] = __builtin_amdgcn_fdot2_f32_bf16(p, p, ss[2 * q], false);
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -333,8 +333,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void conv_mfma_kernel(const C
         const long long e = ((long long)(n * g.OH + oh) * g.OW + ow) * a.out_cs + co;
         bf16x8 v = *(const bf16x8*)(s_out + row * OS + part * 16);
         if constexpr (STATS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+            pair_sums(v, st_s, st_ss);
         }
         if (a.out_mask) {
             const unsigned m = a.out_mask[e >> 3];

@@ -133,8 +133,7 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(const PwsArgs a) {
         for (int i = 0; i < 32 / RSTEP; ++i) {
             const int row = i * RSTEP + row_in;
             const bf16x8 v = *(const bf16x8*)(stg + row * OS + part * 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+            pair_sums(v, st_s, st_ss);
             st_at(ob, (unsigned)((s * 32 + row) * a.out_cs + part * 8) * 2, v);
         }
         wave_lds_fence();

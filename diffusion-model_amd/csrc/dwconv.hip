@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__
             for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[q][j];
             *(bf16x8*)(y + ((n * H + hy) * W + wx + q) * C + c) = o;
             if constexpr (STATS) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+                pair_sums(o, st_s, st_ss);
             }
         }
         if constexpr (STATS) {
@@ -324,8 +323,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_affine_kernel(const bf16* __
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[q][j];
             *(bf16x8*)(y + (((long long)n * H + hy) * W + wx + q) * C + c) = o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; st_s[j >> 1] += f; st_ss[j >> 1] += f * f; }
+            pair_sums(o, st_s, st_ss);
         }
         // the step's GroupNorm sums, exactly as dwconv3x3_kernel<4, true> leaves them for its round
         for (int o = cvs; o < 64; o <<= 1) {

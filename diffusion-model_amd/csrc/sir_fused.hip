@@ -216,8 +216,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
         for (int k = 0; k < E1::NV; ++k) {
             const int row = r1 + k * E1::RPP;
             if (raw_out && live(row)) *(bf16x8*)(raw_out + (row0 + row) * E + v1 * 8) = xr[k];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)xr[k][j]; s[j] += f; ss[j] += f * f; }
+            pair_sums(xr[k], s, ss);
             if constexpr (IPW > 1) {
                 group_store<E, M>(s, ss, k * NWV + wave, v1, lane, s_part);
 #pragma unroll
@@ -345,8 +344,7 @@ __device__ __forceinline__ void sir_fwd_body(const SirArgs& a, char* smem) {
             xo[k] = *(const bf16x8*)(s_x + row * XS + v3 * 16);
             const long long e = (row0 + row) * C + v3 * 8;
             if (rec && live(row)) *(bf16x8*)(a.raw_o + e) = xo[k];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
+            pair_sums(xo[k], s, ss);
             if constexpr (IPW > 1) {
                 group_store<C, M>(s, ss, k * NWV + wave, v3, lane, s_part);
 #pragma unroll
@@ -503,8 +501,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
         for (int k = 0; k < E1::NV; ++k) {
             const int row = r1 + k * E1::RPP;
             if (raw_out) st_at(raw_out, (unsigned)(row * E + v1 * 8) * 2, xr[k]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)xr[k][j]; s[j] += f; ss[j] += f * f; }
+            pair_sums(xr[k], s, ss);
         }
         group_store<E, M>(s, ss, wave, v1, lane, s_part);
         // the tile stays packed (bf16) across the barriers: without this the fp32 copies made for the sums above are kept
@@ -647,8 +644,7 @@ __device__ __forceinline__ void sir_fwd_big_body(const SirArgs& a, char* smem) {
             const int row = r3 + k * E3::RPP;
             xo[k] = *(const bf16x8*)(s_e + row * XS + v3 * 16);
             if (rec) st_at(raw_ob, (unsigned)(row * C + v3 * 8) * 2, xo[k]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)xo[k][j]; s[j] += f; ss[j] += f * f; }
+            pair_sums(xo[k], s, ss);
         }
         group_store<C, M>(s, ss, wave, v3, lane, s_part);
         bf16x8 rx[E3::NV];

