@@ -2,7 +2,8 @@
 //
 // On the implicit-GEMM kernel such a layer computes a 32-wide MFMA tile to keep one column of it and is bound by the
 // staging of its input; here a thread owns one output pixel, the input patch of a 8 x 32 pixel tile (with halo) sits in
-// LDS, and the 288 (x Cout) multiply-adds per pixel run on the vector ALUs against weights broadcast from LDS.
+// LDS, and the 288 (x Cout) multiply-adds per pixel run on the vector ALUs as packed-bf16 dot products against weights held
+// in scalar registers.
 // Same operands as ddpm_conv_forward (packed bf16 weights [9][w_rows][Cin], fp32 bias), products of bf16 values
 // accumulated in fp32 like the MFMA path (the summation order differs).
 #include "conv_geom.h"
@@ -22,7 +23,6 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
     const int PS = a.Cin * 2 + 16;                                // patch pixel stride in bytes (16 B pad against bank conflicts)
     constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
     char* s_patch = smem;                                          // [PH][PW][PS]
-    float* s_w = (float*)(smem + PH * PW * PS);                    // [Cout][9][Cin]
     const int tid = threadIdx.x;
     const int tiles_w = (a.W + THIN_TW - 1) / THIN_TW, tiles_h = (a.H + THIN_TH - 1) / THIN_TH;
     int t = blockIdx.x;
@@ -32,10 +32,6 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
     const int y0 = thi * THIN_TH, x0 = twi * THIN_TW;
     const int vpp = a.Cin / 8;                                     // 16-byte vectors per pixel
 
-    for (int i = tid; i < a.Cout * 9 * a.Cin; i += 256) {
-        const int co = i / (9 * a.Cin), r = i - co * 9 * a.Cin, tap = r / a.Cin, ci = r - tap * a.Cin;
-        s_w[i] = (float)a.w[((long long)tap * a.w_rows + co) * a.Cin + ci];
-    }
     const int items = PH * PW * vpp;
     for (int base = tid; base < items; base += 256 * 6) {
         bf16x8 v[6];
@@ -62,27 +58,28 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
         }
     }
     __syncthreads();
+    // (input widths the matrix-core variant below does not take)  v_dot2c_f32_bf16 multiplies two channel pairs of packed bf16
+    // and accumulates in fp32: no unpacking of the patch, two multiply-adds per instruction, products exact as on the matrix cores.
     const int ty = tid / THIN_TW, tx = tid % THIN_TW;
     float acc[THIN_MAXCO];
 #pragma unroll
     for (int co = 0; co < THIN_MAXCO; ++co) acc[co] = 0.f;
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - dy * 3;
         const char* pp = s_patch + ((ty + dy) * PW + tx + dx) * PS;
+        const bf16* wt = a.w + (long long)tap * a.w_rows * a.Cin;
         for (int part = 0; part < vpp; ++part) {
             const bf16x8 xv = *(const bf16x8*)(pp + part * 16);
-            float xf[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xf[j] = (float)xv[j];
 #pragma unroll
             for (int co = 0; co < THIN_MAXCO; ++co) {
                 if (co < a.Cout) {
-                    const float* wp = s_w + (co * 9 + tap) * a.Cin + part * 8;
-                    const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+                    const bf16x8 wv = *(const bf16x8*)(wt + co * a.Cin + part * 8);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[co] += xf[j] * w0[j];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[co] += xf[4 + j] * w1[j];
+                    for (int q = 0; q < 4; ++q) {
+                        const bf16x2 wp = {wv[2 * q], wv[2 * q + 1]}, xp = {xv[2 * q], xv[2 * q + 1]};
+                        acc[co] = __builtin_amdgcn_fdot2_f32_bf16(wp, xp, acc[co], false);
+                    }
                 }
             }
         }
@@ -93,6 +90,94 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
         for (int co = 0; co < THIN_MAXCO; ++co)
             if (co < a.Cout)
                 a.out[(((long long)n * a.Cout + co) * a.H + oy) * a.W + ox] = act_fwd(acc[co] + (a.bias ? a.bias[co] : 0.f), a.act);
+    }
+}
+
+// The same on the matrix cores, for 16 / 32 / 64 input channels.  Measured on the vector-ALU kernel above (128x128, 256 images):
+// 94 us go to staging the patches, 150 us to the arithmetic, and that arithmetic is bound by the weight operands (every lane
+// needs the same 9 x Cin x Cout values: as broadcast loads they keep the vector memory path busy, as LDS reads the LDS).  A
+// 32 x 32 x 16 MFMA with the weights as its A operand (rows = output channels, rows >= Cout zero) wastes 29 of 32 rows and is
+// still several times cheaper: the weights live in registers for the life of the wave, the patch is read once per tap and
+// 16 channels in operand layout, and a lane ends up with the Cout results of ITS pixel in the first accumulator registers,
+// so the fp32 NCHW stores of a wave are whole 128-byte rows.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_thin_out_mfma_kernel(const ThinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CIN = KS * 16, PS = CIN * 2 + 16, vpp = CIN / 8;
+    constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
+    char* s_patch = smem;                                          // [PH][PW][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_w = (a.W + THIN_TW - 1) / THIN_TW, tiles_h = (a.H + THIN_TH - 1) / THIN_TH;
+    int t = blockIdx.x;
+    const int twi = t % tiles_w; t /= tiles_w;
+    const int thi = t % tiles_h;
+    const int n = t / tiles_h;
+    const int y0 = thi * THIN_TH, x0 = twi * THIN_TW;
+
+    constexpr int items = PH * PW * vpp;
+    for (int base = tid; base < items; base += 256 * 6) {
+        bf16x8 v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int it = base + u * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+            if (it < items) {
+                const int p = it / vpp, part = it - p * vpp;
+                const int py = p / PW, px = p - py * PW;
+                const int iy = y0 + py - 1, ix = x0 + px - 1;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    v[u] = *(const bf16x8*)(a.in + (((long long)n * a.H + iy) * a.W + ix) * CIN + part * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int it = base + u * 256;
+            if (it < items) {
+                const int p = it / vpp, part = it - p * vpp;
+                *(bf16x8*)(s_patch + p * PS + part * 16) = v[u];
+            }
+        }
+    }
+    // weights: lane = output channel (lane & 31), 8 input channels at 16 * ks + 8 * (lane >> 5) of every tap
+    bf16x8 wf[9][KS];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[tap][ks][j] = (bf16)0.f;
+            if ((lane & 31) < a.Cout)
+                wf[tap][ks] = *(const bf16x8*)(a.w + ((long long)tap * a.w_rows + (lane & 31)) * CIN + ks * 16 + (lane >> 5) * 8);
+        }
+    float bias[THIN_MAXCO];
+#pragma unroll
+    for (int co = 0; co < THIN_MAXCO; ++co) bias[co] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    __syncthreads();
+    // a wave owns two of the tile's eight rows; B operand = the 32 pixels of a row (column = pixel), shifted by the tap
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ty = wave * 2 + rr;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const char* pp = s_patch + ((ty + dy) * PW + (lane & 31) + dx) * PS + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xv = *(const bf16x8*)(pp + ks * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][ks], xv, acc, 0, 0, 0);
+            }
+        }
+        // accumulator element r of a lane < 32 = output channel r (0 .. 3) of pixel (ty, lane)
+        const int oy = y0 + ty, ox = x0 + lane;
+        if (lane < 32 && oy < a.H && ox < a.W) {
+#pragma unroll
+            for (int co = 0; co < THIN_MAXCO; ++co)
+                if (co < a.Cout) a.out[(((long long)n * a.Cout + co) * a.H + oy) * a.W + ox] = act_fwd(acc[co] + bias[co], a.act);
+        }
     }
 }
 
@@ -213,9 +298,12 @@ int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream) {
     ThinArgs a;
     a.in = (const bf16*)d->in0; a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (float*)d->out;
     a.N = d->N; a.H = d->IH; a.W = d->IW; a.Cin = d->C0; a.Cout = d->Cout; a.w_rows = d->w_rows; a.act = d->act;
-    const size_t lds = (size_t)(THIN_TH + 2) * (THIN_TW + 2) * (d->C0 * 2 + 16) + (size_t)d->Cout * 9 * d->C0 * 4;
+    const size_t lds = (size_t)(THIN_TH + 2) * (THIN_TW + 2) * (d->C0 * 2 + 16);
     const long long tiles = (long long)d->N * ((d->IH + THIN_TH - 1) / THIN_TH) * ((d->IW + THIN_TW - 1) / THIN_TW);
     if (lds > 64 * 1024 || tiles > 0x7fffffffll) return 0;
-    hipLaunchKernelGGL(conv_thin_out_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    if (d->C0 == 16) hipLaunchKernelGGL(conv_thin_out_mfma_kernel<1>, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    else if (d->C0 == 32) hipLaunchKernelGGL(conv_thin_out_mfma_kernel<2>, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    else if (d->C0 == 64) hipLaunchKernelGGL(conv_thin_out_mfma_kernel<4>, dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(conv_thin_out_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, a);
     return ddpm_check_launch("conv_thin") == DDPM_OK ? 1 : -1;
 }

@@ -105,9 +105,11 @@ def test_conv_fused_input_and_epilogue(dev):
     assert_rel(nchw(y), ref, 1.5e-2)
 
 
-@pytest.mark.parametrize("n,ci,co,h,wd", [(2, 32, 3, 16, 16), (3, 32, 1, 32, 32), (1, 32, 3, 20, 72), (2, 64, 4, 8, 40), (1, 32, 1, 128, 128)])
+@pytest.mark.parametrize("n,ci,co,h,wd", [(2, 32, 3, 16, 16), (3, 32, 1, 32, 32), (1, 32, 3, 20, 72), (2, 64, 4, 8, 40), (1, 32, 1, 128, 128),
+                                            (2, 16, 3, 24, 40), (2, 48, 2, 16, 16), (3, 32, 2, 64, 64)])
 def test_conv_head_f32_nchw_tanh(dev, n, ci, co, h, wd):
-    """the image head (few output channels, tanh, fp32 NCHW): the vector-ALU kernel, ragged tiles included"""
+    """the image head (few output channels, tanh, fp32 NCHW): the matrix-core kernel with zero-padded weight rows (16 / 32 / 64
+    input channels) and the vector-ALU kernel (48 here), ragged tiles included"""
     x = r16(hash_normal((n, ci, h, wd), 1))
     w = r16(hash_normal((co, ci, 3, 3), 2) * 0.06)
     b = hash_normal((co,), 3) * 0.1
