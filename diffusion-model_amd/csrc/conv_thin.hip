@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const ThinArgs a) {
 // 16 channels in operand layout, and a lane ends up with the Cout results of ITS pixel in the first accumulator registers,
 // so the fp32 NCHW stores of a wave are whole 128-byte rows.
 template <int KS>
-__global__ __launch_bounds__(256) void conv_thin_out_mfma_kernel(const ThinArgs a) {
+__global__ __launch_bounds__(256, KS <= 2 ? 4 : 2) void conv_thin_out_mfma_kernel(const ThinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CIN = KS * 16, PS = CIN * 2 + 16, vpp = CIN / 8;
     constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void conv_thin_out_mfma_kernel(const ThinArgs 
 }
 
 // The mirror case: very few INPUT channels that matter (the stem: the image's 1 or 3 channels, stored zero-padded to 16;
-// and the head's data-gradient, whose input is the gradient of those channels), 32 output channels.  A thread owns one
-// pixel and its 32 accumulators; the patch keeps only the channels the caller declares as used (C0_used).
+// and the head's data-gradient, whose input is the gradient of those channels), 32 output channels.  The patch keeps only the
+// channels the caller declares as used (C0_used, at most 4); the products run on the matrix cores with K = taps x 4 channels.
 struct ThinInArgs {
     const bf16* in; const bf16* w; const float* bias; bf16* out; bf16* out2;
     int N, H, W, Cin, Cused, Cout, out_cs, w_rows, act, act2;
@@ -192,7 +192,6 @@ struct ThinInArgs {
 __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
     constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
     __shared__ __attribute__((aligned(16))) bf16 s_patch[PH * PW][4];
-    __shared__ __attribute__((aligned(16))) float s_w[9 * 4 * 32];             // [tap][ci][co]
     const int tid = threadIdx.x;
     const int tiles_w = (a.W + THIN_TW - 1) / THIN_TW, tiles_h = (a.H + THIN_TH - 1) / THIN_TH;
     int t = blockIdx.x;
@@ -200,51 +199,78 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ThinInArgs a) {
     const int thi = t % tiles_h;
     const int n = t / tiles_h;
     const int y0 = thi * THIN_TH, x0 = twi * THIN_TW;
-    for (int i = tid; i < 9 * 4 * 32; i += 256) {
-        const int tap = i / 128, r = i - tap * 128, ci = r / 32, co = r - ci * 32;
-        s_w[i] = (ci < a.Cused && co < a.Cout) ? (float)a.w[((long long)tap * a.w_rows + co) * a.Cin + ci] : 0.f;
-    }
-    for (int p = tid; p < PH * PW; p += 256) {
-        const int py = p / PW, px = p - py * PW;
-        const int iy = y0 + py - 1, ix = x0 + px - 1;
-        bf16x4 v;
+    // K = (tap, channel) pairs: k = 4 * tap + ci, 36 of them padded to three 16-wide steps.  A operand (row = output channel):
+    // the 8 values of a lane are the first four input channels of two neighbouring taps (8 contiguous bytes each in the
+    // weight tensor), requested here, ahead of the patch, and cleared where the channel is not in use
+    const int lane = tid & 63, wave = tid >> 6;
+    bf16x8 wf[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16)0.f;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const bf16x4*)(a.in + (((long long)n * a.H + iy) * a.W + ix) * a.Cin);
-        *(bf16x4*)s_patch[p] = v;
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tap = ks * 4 + (lane >> 5) * 2 + h, co = lane & 31;
+            bf16x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (bf16)0.f;
+            if (tap < 9 && co < a.Cout) v = *(const bf16x4*)(a.w + ((long long)tap * a.w_rows + co) * a.Cin);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[ks][h * 4 + j] = j < a.Cused ? v[j] : (bf16)0.f;
+        }
+    {
+        // 340 patch pixels, 256 threads: both of a thread's loads are in flight before the first is stored
+        bf16x4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = tid + u * 256;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = y0 + py - 1, ix = x0 + px - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] = (bf16)0.f;
+            if (p < PH * PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v[u] = *(const bf16x4*)(a.in + (((long long)n * a.H + iy) * a.W + ix) * a.Cin);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * 256 < PH * PW) *(bf16x4*)s_patch[tid + u * 256] = v[u];
     }
     __syncthreads();
-    const int ty = tid / THIN_TW, tx = tid % THIN_TW;
-    float acc[32];
-#pragma unroll
-    for (int co = 0; co < 32; ++co) acc[co] = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const bf16x4 xv = *(const bf16x4*)s_patch[(ty + dy) * PW + tx + dx];
-        for (int ci = 0; ci < a.Cused; ++ci) {
-            const float x = (float)xv[ci];
-            const float* wp = s_w + (tap * 4 + ci) * 32;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 w4 = *(const f32x4*)(wp + q * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[q * 4 + j] += x * w4[j];
-            }
-        }
-    }
-    // results through LDS, so that consecutive lanes store consecutive 16-byte pieces (a thread's own 64 bytes, stored
-    // directly, would make every store instruction touch 64 different lines)
+    // B operand (column = pixel): the 4-channel vectors of the same two taps.  Three matrix instructions per 32 pixels replace
+    // 27 .. 36 x 32 multiply-adds per pixel on the vector ALUs.
+    // results through LDS, so that consecutive lanes store consecutive 16-byte pieces
     __shared__ __attribute__((aligned(16))) char s_out[256 * 80];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bf16x8 o;
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ty = wave * 2 + rr, tx = lane & 31;
+        f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int co = q * 8 + j;
-            const float v = acc[co] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
-            o[j] = (bf16)(a.act == ACT_NONE ? v : act_fwd(v, a.act));      // the stem hands its activated result out as out2
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            bf16x8 xv;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tap = ks * 4 + (lane >> 5) * 2 + h;
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (bf16)0.f;
+                if (tap < 9) v = *(const bf16x4*)s_patch[(ty + tap / 3) * PW + tx + tap % 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[h * 4 + j] = v[j];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xv, acc, 0, 0, 0);
         }
-        *(bf16x8*)(s_out + tid * 80 + q * 16) = o;
+        // accumulator element r = output channel (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) of pixel (ty, tx)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = q * 8 + 4 * (lane >> 5);
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[4 * q + j] + ((a.bias && c0 + j < a.Cout) ? a.bias[c0 + j] : 0.f);
+                o[j] = (bf16)(a.act == ACT_NONE ? v : act_fwd(v, a.act));      // the stem hands its activated result out as out2
+            }
+            *(bf16x4*)(s_out + (ty * THIN_TW + tx) * 80 + c0 * 2) = o;
+        }
     }
     __syncthreads();
 #pragma unroll
