@@ -117,9 +117,10 @@ extern "C" int ddpm_q_sample(const float* x0, const int64_t* t_, const float* no
 // reverse step: x_{t-1} = A_t x_t + B_t x0_pred + C_t z        (reference ddpm.py:138-144)
 // A_t = (1-abar_{t-1}) sqrt(alpha_t)/(1-abar_t), B_t = sqrt(abar_{t-1}) beta_t/(1-abar_t),
 // C_t = sqrt(1-abar_{t-1}) sqrt(beta_t/(1-abar_t)); C_1 = 0 so the last step adds no noise.
-__global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restrict__ xt, const float* __restrict__ x0p,
+// (out may be xt: every element is read and written by the same thread, and neither pointer is declared restrict)
+__global__ __launch_bounds__(256) void reverse_step_kernel(const float* xt, const float* __restrict__ x0p,
                                                             const long long* __restrict__ t, const float* __restrict__ noise,
-                                                            const float* __restrict__ sched, float* __restrict__ out, int N, long long chw,
+                                                            const float* __restrict__ sched, float* out, int N, long long chw,
                                                             const unsigned long long* __restrict__ seed, unsigned stream_id,
                                                             int sigmoid_pred, unsigned long long q0) {
     const long long total4 = (long long)N * chw / 4;

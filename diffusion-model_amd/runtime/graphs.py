@@ -495,7 +495,6 @@ class GraphedSampler:
         self.first_index = int(first_image) * (self.x.numel() // n)
         if self.first_index % 4:
             raise ValueError("GraphedSampler: first_image * C * H * W must be a multiple of 4")
-        self.x_next = torch.empty_like(self.x)
         self.times = torch.zeros(n, device=dev, dtype=torch.long)
         self.graph = None
         self.bce = ddpm.reconstruction_method == "bce"
@@ -544,9 +543,9 @@ class GraphedSampler:
 
     def _body(self):
         x0_pred = self._forward()
-        self.ddpm.reverse_q(self.x, x0_pred, self.times, out=self.x_next, _sigmoid=self.bce, _seed=self.seed,
+        # in place: the step kernel reads and writes every element in the same thread (one copy per step less)
+        self.ddpm.reverse_q(self.x, x0_pred, self.times, out=self.x, _sigmoid=self.bce, _seed=self.seed,
                             _first_index=self.first_index)
-        self.x.copy_(self.x_next)
         self.times -= 1
 
     @torch.no_grad()

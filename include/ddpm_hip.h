@@ -71,7 +71,7 @@ int ddpm_train_head(const float* x0, const int64_t* t_in, const float* noise, co
 /* DDPM.reverse_q (ddpm.py:113-144): out = A_t x_t + B_t x0_pred + C_t z.  sigmoid_pred applies the "bce" branch
  * of DDPM.sample (ddpm.py:158-159) to x0_pred first.  z drawn in-kernel (noise == NULL) is the Philox sample of GLOBAL flat
  * element first_index + i (a multiple of 4): a rank that holds images [b, e) of a sharded sampling job passes
- * first_index = b * chw and draws exactly the numbers a single GPU would draw for those images. */
+ * first_index = b * chw and draws exactly the numbers a single GPU would draw for those images.  out may be xt (in place). */
 int ddpm_reverse_step(const float* xt, const float* x0_pred, const int64_t* t, const float* noise, const float* sched,
                       float* out, int N, int64_t chw, const uint64_t* seed, uint32_t stream_id, int sigmoid_pred,
                       uint64_t first_index, ddpm_stream_t stream);
