@@ -315,9 +315,152 @@ static int conv_thin_in_try(const ddpm_conv_desc* d, hipStream_t stream) {
     return ddpm_check_launch("conv_thin_in") == DDPM_OK ? 1 : -1;
 }
 
+// 3x3 stride 1 from 32 to 32 channels (the last feature convolution in front of the head, its data-gradient, and the
+// full-resolution convolutions of the first stage): the same skeleton with a full operand.  The general tap-list kernel spends
+// most of such a launch on its per-tile bookkeeping (pixel table, weights staged to LDS for every 128-position tile); here the
+// nine 32 x 32 weight slices sit in registers as A operands (72 registers), a workgroup stages one 8 x 32 pixel patch, and each
+// wave runs 18 matrix instructions per row of 32 pixels.  Epilogue as for the stem: bias, activation, optional residual,
+// optional second (activated) result, 16-byte NHWC stores through LDS.
+struct C32Args {
+    const bf16* in; const bf16* w; const float* bias; bf16* out; bf16* out2; const bf16* res;
+    int N, H, W, out_cs, w_rows, act, act2;
+};
+
+__global__ __launch_bounds__(256, 4) void conv3x3_c32_kernel(const C32Args a) {
+    constexpr int CIN = 32, PS = CIN * 2 + 16, vpp = CIN / 8;
+    constexpr int PW = THIN_TW + 2, PH = THIN_TH + 2;
+    __shared__ __attribute__((aligned(16))) char smem[PH * PW * PS];      // the patch; afterwards the output tile [256][80]
+    char* s_patch = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_w = (a.W + THIN_TW - 1) / THIN_TW, tiles_h = (a.H + THIN_TH - 1) / THIN_TH;
+    int t = blockIdx.x;
+    const int twi = t % tiles_w; t /= tiles_w;
+    const int thi = t % tiles_h;
+    const int n = t / tiles_h;
+    const int y0 = thi * THIN_TH, x0 = twi * THIN_TW;
+
+    constexpr int items = PH * PW * vpp;
+    for (int base = tid; base < items; base += 256 * 6) {
+        bf16x8 v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int it = base + u * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
+            if (it < items) {
+                const int p = it / vpp, part = it - p * vpp;
+                const int py = p / PW, px = p - py * PW;
+                const int iy = y0 + py - 1, ix = x0 + px - 1;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    v[u] = *(const bf16x8*)(a.in + (((long long)n * a.H + iy) * a.W + ix) * CIN + part * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int it = base + u * 256;
+            if (it < items) {
+                const int p = it / vpp, part = it - p * vpp;
+                *(bf16x8*)(s_patch + p * PS + part * 16) = v[u];
+            }
+        }
+    }
+    bf16x8 wf[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wf[tap][ks] = *(const bf16x8*)(a.w + ((long long)tap * a.w_rows + (lane & 31)) * CIN + ks * 16 + (lane >> 5) * 8);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ty = wave * 2 + rr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const char* pp = s_patch + ((ty + dy) * PW + (lane & 31) + dx) * PS + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 xv = *(const bf16x8*)(pp + ks * 32);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][ks], xv, acc[rr], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // every wave is done with the patch: its LDS becomes the output tile
+    char* s_out = smem;
+    // accumulator element r = output channel (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) of pixel (ty, lane & 31)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ty = wave * 2 + rr, tx = lane & 31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = q * 8 + 4 * (lane >> 5);
+            bf16x4 o;
+            if (a.act == ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[rr][4 * q + j] + (a.bias ? a.bias[c0 + j] : 0.f));
+            } else if (a.act == ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)act_fwd(acc[rr][4 * q + j] + (a.bias ? a.bias[c0 + j] : 0.f), ACT_GELU);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)act_fwd(acc[rr][4 * q + j] + (a.bias ? a.bias[c0 + j] : 0.f), a.act);
+            }
+            *(bf16x4*)(s_out + (ty * THIN_TW + tx) * 80 + c0 * 2) = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int it = tid + k * 256, px = it >> 2, q = it & 3;
+        const int oy = y0 + px / THIN_TW, ox = x0 + px % THIN_TW;
+        if (oy >= a.H || ox >= a.W) continue;
+        bf16x8 o = *(const bf16x8*)(s_out + px * 80 + q * 16);
+        const long long e = (((long long)n * a.H + oy) * a.W + ox) * a.out_cs + q * 8;
+        if (a.res) {
+            const bf16x8 rv = *(const bf16x8*)(a.res + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)o[j] + (float)rv[j]);
+        }
+        *(bf16x8*)(a.out + e) = o;
+        if (a.out2) {                                  // second result: act2 of the (bf16) first one
+            bf16x8 y;
+            if (a.act2 == ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], ACT_GELU);
+            } else if (a.act2 == ACT_SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], ACT_SILU);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = (bf16)act_fwd((float)o[j], a.act2);
+            }
+            *(bf16x8*)(a.out2 + e) = y;
+        }
+    }
+}
+
+static int conv_c32_try(const ddpm_conv_desc* d, hipStream_t stream) {
+    if (d->kind != CONV_3X3_S1 || d->out_mode != OUT_BF16_NHWC || d->C0 != 32 || d->C1 != 0 || d->Cout != 32 || d->CoutW != 32) return 0;
+    if (d->in_add || d->in_mask || d->out_mask || d->sum_out || d->gn_gamma || d->gnb_raw || d->gn_part || d->in_affine || d->C0_used) return 0;
+    if (!d->out || d->out_cs % 8 || d->out_cs < 32 || (d->out2 && (d->act != 0 || d->res))) return 0;
+    if (ACT_HAS_BETA(d->act) || ACT_HAS_BETA(d->act2)) return 0;
+    C32Args a;
+    a.in = (const bf16*)d->in0; a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out; a.out2 = (bf16*)d->out2;
+    a.res = (const bf16*)d->res;
+    a.N = d->N; a.H = d->IH; a.W = d->IW; a.out_cs = d->out_cs; a.w_rows = d->w_rows; a.act = d->act; a.act2 = d->act2;
+    const long long tiles = (long long)d->N * ((d->IH + THIN_TH - 1) / THIN_TH) * ((d->IW + THIN_TW - 1) / THIN_TW);
+    if (tiles > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    return ddpm_check_launch("conv3x3_c32") == DDPM_OK ? 1 : -1;
+}
+
 // Returns 1 when the problem was launched here, 0 when the caller should use the general kernel, < 0 on error.
 int ddpm_conv_thin_try(const ddpm_conv_desc* d, hipStream_t stream) {
     if (const int rc = conv_thin_in_try(d, stream)) return rc;
+    if (const int rc = conv_c32_try(d, stream)) return rc;
     if (d->kind != CONV_3X3_S1 || d->out_mode != OUT_F32_NCHW || d->Cout > THIN_MAXCO || d->C1 != 0) return 0;
     if (d->in_add || d->in_mask || d->out_mask || d->res || d->sum_out || d->gn_gamma) return 0;
     if (d->C0 % 8 || d->C0 > 64) return 0;

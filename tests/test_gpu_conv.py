@@ -119,6 +119,36 @@ def test_conv_head_f32_nchw_tanh(dev, n, ci, co, h, wd):
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,h,wd,act,with_res,second", [(2, 16, 16, "none", False, False), (1, 12, 20, "gelu", False, False), (3, 32, 32, "none", True, False),
+                                                        (2, 40, 72, "none", False, True), (1, 64, 64, "silu", False, False), (5, 8, 8, "none", False, True)])
+def test_conv3x3_32_to_32_kernel(dev, n, h, wd, act, with_res, second):
+    """3x3 stride 1, 32 -> 32 channels: the kernel with all nine weight slices in registers (ragged tiles, activation, residual,
+    second activated result), against torch fp32 on the same bf16 operands"""
+    from oracle import ref_cpu as O
+    x = r16(hash_normal((n, 32, h, wd), 11))
+    w = r16(hash_normal((32, 32, 3, 3), 12) * (1.0 / 288) ** 0.5)
+    b = hash_normal((32,), 13) * 0.2
+    res = r16(hash_normal((n, 32, h, wd), 14))
+    ref = F.conv2d(x, w, b, padding=1)
+    kw = {}
+    if act != "none":
+        kw["act"] = hip.ACT[act]
+        ref = O.act_fn(act)(ref)
+    if with_res:
+        kw["res"] = nhwc(res, dev)
+        ref = r16(ref) + res
+    if second:
+        kw["act2"] = hip.ACT["gelu"]
+    got = ops.conv_forward(hip.CONV_3X3_S1, nhwc(x, dev), pack.pack_fwd(hip.CONV_3X3_S1, w.to(dev)), b.to(dev), 32, **kw)
+    assert hip.lib().ddpm_conv_last_kernel() == 3
+    if second:
+        raw, y = got
+        assert_rel(nchw(raw), ref)
+        assert_rel(nchw(y), F.gelu(nchw(raw)), 8e-3)
+    else:
+        assert_rel(nchw(got), ref)
+
+
 def test_conv_rejects_bad_shapes(dev):
     x = torch.zeros(1, 4, 4, 24, device=dev, dtype=torch.bfloat16)
     w = torch.zeros(1, 32, 24, device=dev, dtype=torch.bfloat16)
