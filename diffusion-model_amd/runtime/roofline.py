@@ -41,7 +41,7 @@ class _Probe:
 # Probe name (what runtime.ops brackets with events: one host-side launch call) -> (family, stream of the pipelined step it
 # runs on, device kernels one such call emits as the profiler names them).  A family merges the instantiations and the
 # large-image variants of one kernel design; the grouped weight-gradient call emits a pointwise kernel and several tap-list
-# kernels, the image-end call one of two kernels.
+# kernels, the image-end call one of its few kernels (stem, head, the 32-channel 3x3 kernel).
 FAMILIES = {
     "sir_fwd_kernel": ("sir_fwd", "main", ("sir_fwd_kernel",)),
     "sir_fwd_big_kernel": ("sir_fwd", "main", ("sir_fwd_big_kernel",)),
@@ -49,7 +49,7 @@ FAMILIES = {
     "sir_bwd_big_kernel": ("sir_bwd", "main", ("sir_bwd_big_kernel",)),
     "conv_wgrad_group_kernel": ("conv_wgrad_group", "side", ("conv_wgrad_group_kernel", "pw_wgrad_group_kernel")),
     "conv_wgrad_kernel": ("conv_wgrad", "side", ("conv_wgrad_kernel", "pw_wgrad_kernel")),
-    "conv_thin_kernel": ("conv_thin", "main", ("conv_thin_in_kernel", "conv_thin_out_kernel")),
+    "conv_thin_kernel": ("conv_thin", "main", ("conv_thin_in_kernel", "conv_thin_out_kernel", "conv_thin_out_mfma_kernel", "conv3x3_c32_kernel")),
     "embed_bwd_kernel": ("embed_bwd", "side", ("embed_bwd_kernel",)),
     "dwconv3x3_wgrad_kernel": ("dwconv3x3_wgrad", "side", ("dwconv3x3_wgrad_kernel",)),
     "unet_lds_kernel": ("unet_lds", "main", ("unet_lds_kernel",)),

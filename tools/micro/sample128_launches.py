@@ -1,5 +1,6 @@
-"""Every launch of one 128x128x3 denoiser forward (self-attention at the 16x16 stage), timed alone with HIP events, largest first:
-python tools/micro/sample128_launches.py [batch]"""
+"""Every launch of one denoiser forward on 3-channel images (128x128 with self-attention at the 16x16 stage by default), timed
+alone with HIP events, largest first:
+python tools/micro/sample128_launches.py [batch [size]]"""
 import os
 import sys
 
@@ -12,9 +13,10 @@ from dm_amd.runtime import ops, roofline  # noqa: E402
 
 dev = torch.device("cuda", 0)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-m = build_model(dev, 3, [2])
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+m = build_model(dev, 3, [2] if size == 128 else [])
 m.eval()
-x = torch.randn(nb, 3, 128, 128, device=dev)
+x = torch.randn(nb, 3, size, size, device=dev)
 t = torch.randint(0, 120, (nb,), device=dev)
 with torch.no_grad():
     m(x[:nb // 2], t[:nb // 2])          # another shape first (one-time set-up); the module replays a graph from a shape's second pass on
