@@ -14,7 +14,8 @@
 //
 // Fused in: bias, the normalise-on-load of the input (per image and channel scale / shift from the producer's partial sums,
 // then none / gelu / silu), the input's dropout mask, and the per-tile GroupNorm sums of the rounded result for the
-// normalisation that follows.
+// normalisation that follows; or (EPI, the data-gradient of the block's expansion) the dropout mask of the result and a tensor
+// added last, with the arithmetic of the tiled kernel's epilogue (mask and sum on the bf16-rounded product).
 #include "conv_geom.h"
 #include "ddpm_hip.h"
 
@@ -26,6 +27,9 @@ struct PwsArgs {
     const unsigned char* in_mask;    // keep bits of the input, one byte per 8 consecutive elements, or null
     float in_mask_scale;
     float* gn_part; int gn_G;        // [N][gn_G][PT][2], or null
+    const bf16* res;                 // EPI: tensor of out's layout added last, or null
+    const unsigned char* out_mask;   // EPI: keep bits of the result (applied before res), one byte per 8 consecutive elements, or null
+    float out_mask_scale;
     int HW, TP, PT, out_cs;          // positions per image, per workgroup; workgroups per image; channel stride of out
 };
 
@@ -38,7 +42,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // PREACT: -1 = the input is used as it is; otherwise the activation code of the normalise-on-load (none / gelu / silu)
-template <int CIN, int COUT, int PREACT>
+// EPI: the result is masked and / or added to a.res on its way out
+template <int CIN, int COUT, int PREACT, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void pw_stream_kernel(const PwsArgs a) {
     constexpr int KS = CIN / 16, NT = COUT / 32, PARTS = COUT / 8;
     constexpr int OS = COUT * 2 + 16;             // row stride of the wave's output tile in LDS (bytes)
@@ -71,6 +76,18 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(const PwsArgs a) {
     char* stg = smem + wave * WAVE_LDS;
     const int part = lane % PARTS, row_in = lane / PARTS;       // this lane's 16-byte column and first row of the output tile
     constexpr int RSTEP = 64 / PARTS;                           // rows covered by one pass of the wave
+    constexpr int NPASS = 32 / RSTEP;
+    const bf16* rb = EPI && a.res ? a.res + pos0 * a.out_cs : nullptr;
+    const unsigned char* omb = EPI && a.out_mask ? a.out_mask + pos0 * a.out_cs / 8 : nullptr;      // (out_cs is a multiple of 8)
+    // what the epilogue adds and masks with, per pass of the wave over its tile: requested one sub-tile ahead, like the input
+    auto load_epi = [&](int s, bf16x8 (&rv)[NPASS], unsigned (&om)[NPASS]) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const unsigned off = (unsigned)((s * 32 + i * RSTEP + row_in) * a.out_cs + part * 8);
+            if (rb) rv[i] = ld_at<bf16x8>(rb, off * 2);
+            if (omb) om[i] = ld_at<unsigned char>(omb, off >> 3);
+        }
+    };
 
     // (the keep bits of a vector sit at its element offset / 8: one byte per lane and 16 input channels, fetched with the data)
     auto load = [&](int s, bf16x8 (&v)[KS], unsigned (&m)[KS]) {
@@ -84,12 +101,18 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(const PwsArgs a) {
     bf16x8 xr[KS];
     unsigned mr[KS] = {};
     load(wave, xr, mr);
+    bf16x8 rr[NPASS] = {};
+    unsigned orr[NPASS] = {};
+    if constexpr (EPI) load_epi(wave, rr, orr);
     float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_ss[4] = {0.f, 0.f, 0.f, 0.f};
 
     for (int s = wave; s < nsub; s += 4) {
         bf16x8 xn[KS];
         unsigned mn[KS] = {};
         load(s + 4 < nsub ? s + 4 : s, xn, mn);   // (the last trip re-reads its own positions: one cached kilobyte)
+        bf16x8 rn[NPASS] = {};
+        unsigned on[NPASS] = {};
+        if constexpr (EPI) load_epi(s + 4 < nsub ? s + 4 : s, rn, on);
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -132,13 +155,27 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(const PwsArgs a) {
 #pragma unroll
         for (int i = 0; i < 32 / RSTEP; ++i) {
             const int row = i * RSTEP + row_in;
-            const bf16x8 v = *(const bf16x8*)(stg + row * OS + part * 16);
+            bf16x8 v = *(const bf16x8*)(stg + row * OS + part * 16);
             pair_sums(v, st_s, st_ss);
+            if constexpr (EPI) {
+                if (omb) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (orr[i] >> j) & 1 ? (bf16)((float)v[j] * a.out_mask_scale) : (bf16)0.f;
+                }
+                if (rb) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)rr[i][j]);
+                }
+            }
             st_at(ob, (unsigned)((s * 32 + row) * a.out_cs + part * 8) * 2, v);
         }
         wave_lds_fence();
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) { xr[kk] = xn[kk]; mr[kk] = mn[kk]; }
+        if constexpr (EPI) {
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) { rr[i] = rn[i]; orr[i] = on[i]; }
+        }
     }
 
     if (a.gn_part) {
@@ -170,15 +207,16 @@ __global__ __launch_bounds__(256, 2) void pw_stream_kernel(const PwsArgs a) {
     }
 }
 
-template <int CIN, int COUT, int PREACT>
+template <int CIN, int COUT, int PREACT, bool EPI = false>
 int pws_launch(const PwsArgs& a, int N, hipStream_t stream) {
     constexpr size_t lds = 4 * 32 * (COUT * 2 + 16) + COUT * 4 + CIN * 8;
-    hipLaunchKernelGGL((pw_stream_kernel<CIN, COUT, PREACT>), dim3((unsigned)(N * a.PT)), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((pw_stream_kernel<CIN, COUT, PREACT, EPI>), dim3((unsigned)(N * a.PT)), dim3(256), lds, stream, a);
     return ddpm_check_launch("conv_pw_stream");
 }
 
 template <int CIN, int COUT>
 int pws_launch_act(const PwsArgs& a, int N, int act, hipStream_t stream) {
+    if (a.res || a.out_mask) return pws_launch<CIN, COUT, -1, true>(a, N, stream);      // (never together with in_gn: pws_plan)
     if (!a.in_gn) return pws_launch<CIN, COUT, -1>(a, N, stream);
     if (act == ACT_GELU) return pws_launch<CIN, COUT, ACT_GELU>(a, N, stream);
     if (act == ACT_SILU) return pws_launch<CIN, COUT, ACT_SILU>(a, N, stream);
@@ -190,7 +228,8 @@ thread_local int g_pws_mode = 0;              // 0: by problem size; 1: wherever
 // Positions per workgroup for a problem this kernel takes, 0 for every other problem.
 int pws_plan(const ddpm_conv_desc* d) {
     if (g_pws_mode < 0) return 0;
-    if (d->kind != CONV_1X1 || d->C1 || d->in1 || d->in_add || d->out_mask || d->res || d->act != ACT_NONE) return 0;
+    if (d->kind != CONV_1X1 || d->C1 || d->in1 || d->in_add || d->act != ACT_NONE) return 0;
+    if ((d->out_mask || d->res) && (d->in_affine || d->gn_part_groups > 0)) return 0;
     if (d->out_mode != OUT_BF16_NHWC || !d->out || d->out2 || d->sum_out || d->gn_gamma || d->gnb_raw || d->C0_used) return 0;
     if (d->Cout != d->CoutW || d->out_cs % 8 || d->out_cs < d->Cout) return 0;
     const int ci = d->C0, co = d->Cout;
@@ -236,6 +275,7 @@ int ddpm_conv_pw_stream_try(const ddpm_conv_desc* d, hipStream_t stream) {
     a.x = (const bf16*)d->in0; a.w = (const bf16*)d->w; a.bias = d->bias; a.out = (bf16*)d->out;
     a.in_gn = d->in_affine; a.in_mask = d->in_mask; a.in_mask_scale = d->in_mask_scale;
     a.gn_part = d->gn_part; a.gn_G = d->gn_part ? d->gn_part_groups : 0;
+    a.res = (const bf16*)d->res; a.out_mask = d->out_mask; a.out_mask_scale = d->out_mask_scale;
     a.HW = d->IH * d->IW; a.TP = tp; a.PT = a.HW / tp; a.out_cs = d->out_cs;
     int rc = DDPM_EINVAL;
 #define PWS_CASE(CI, CO) if (d->C0 == CI && d->Cout == CO) rc = pws_launch_act<CI, CO>(a, d->N, d->in_affine_act, stream);

@@ -267,7 +267,12 @@ struct PwArgs {
 
 #define PW_ROWS 64
 #define PW_RS 272             // LDS row stride in bytes: 128 channels + 16 bytes of padding
+#define PW_RS_NARROW 144      // the same for problems of at most 64 x 64 channels (64 channels + 16 bytes of padding)
+#define PW_NARROW_MAX 64
 
+// NACC: 32x32 tile pairs per wave (4 covers 128 x 128 channels, 1 covers 64 x 64); NSLOT: 16-byte vectors per thread and chunk
+// (8 covers 64 rows of 128 + 128 channels, 4 covers 64 + 64).  The narrow form needs a third of the registers.
+template <int RS, int NACC, int NSLOT>
 __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int by, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cb = by / a.nib, ib = by - cb * a.nib;
@@ -279,9 +284,9 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
     const long long r_begin = (long long)bx * a.rows_per_split;
     const long long r_end = min(a.R, r_begin + a.rows_per_split);
 
-    f32x16 acc[4];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -290,21 +295,21 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
 
     // per-thread slots of a chunk (the same for every chunk): row, global element offset inside the chunk, LDS offset;
     // computed once - the integer divisions would otherwise cost more than the MFMAs of a chunk
-    bf16x8 v[8];
-    int s_row[8], s_goff[8], s_lds[8];
+    bf16x8 v[NSLOT];
+    int s_row[NSLOT], s_goff[NSLOT], s_lds[NSLOT];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NSLOT; ++u) {
         const int it = tid + u * 256;
         s_row[u] = -1; s_goff[u] = 0; s_lds[u] = 0;
         if (it < nx) {
             const int row = it / xv, c = (it - row * xv) * 8;
-            s_row[u] = row; s_goff[u] = row * a.Cin + ci0 + c; s_lds[u] = row * PW_RS + c * 2;
+            s_row[u] = row; s_goff[u] = row * a.Cin + ci0 + c; s_lds[u] = row * RS + c * 2;
         } else if (it < nitems) {
             const int di = it - nx;
             const int row = di / dv, c = (di - row * dv) * 8;
             if (co0 + c + 8 <= a.dy_cs) { s_row[u] = row | 0x10000; s_goff[u] = row * a.dy_cs + co0 + c; }
             else s_row[u] = -2;                                    // padded output channels: zeros
-            s_lds[u] = (PW_ROWS + row) * PW_RS + c * 2;
+            s_lds[u] = (PW_ROWS + row) * RS + c * 2;
         }
     }
     const bf16* xg = a.x;
@@ -314,7 +319,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
     const long long x_rs = a.Cin, d_rs = a.dy_cs;
     auto fetch = [&](long long r0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NSLOT; ++u) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[u][j] = (bf16)0.f;
             if (s_row[u] < 0) continue;
@@ -335,21 +340,21 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
     };
     auto stash = [&](char* b) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < NSLOT; ++u)
             if (s_row[u] != -1) *(bf16x8*)(b + s_lds[u]) = v[u];
     };
 
     if (r_begin < r_end) fetch(r_begin);
     int par = 0;
     for (long long r0 = r_begin; r0 < r_end; r0 += PW_ROWS, par ^= 1) {
-        char* b = smem + par * (2 * PW_ROWS * PW_RS);       // each buffer: X rows, then dY rows
+        char* b = smem + par * (2 * PW_ROWS * RS);       // each buffer: X rows, then dY rows
         stash(b);
         if (r0 + PW_ROWS < r_end) fetch(r0 + PW_ROWS);
         __syncthreads();
         const char* sx = b;
-        const char* sd = b + PW_ROWS * PW_RS;
+        const char* sd = b + PW_ROWS * RS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NACC; ++i) {
             const int pr = wave + 4 * i;
             if (pr < npairs) {
                 const int ct = pr / nit, itile = pr - ct * nit;
@@ -358,15 +363,15 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
 #pragma unroll
                 for (int ks = 0; ks < PW_ROWS / 16; ++ks) {
                     const int k = ks * 16 + kq;
-                    const bf16x8 av = tr_frag(dyp + k * PW_RS, dyp + (k + 4) * PW_RS);
-                    const bf16x8 bv = tr_frag(xp + k * PW_RS, xp + (k + 4) * PW_RS);
+                    const bf16x8 av = tr_frag(dyp + k * RS, dyp + (k + 4) * RS);
+                    const bf16x8 bv = tr_frag(xp + k * RS, xp + (k + 4) * RS);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
                 }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NACC; ++i) {
         const int pr = wave + 4 * i;
         if (pr >= npairs) continue;
         const int ct = pr / nit, itile = pr - ct * nit;
@@ -385,9 +390,13 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
 
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    pw_body(a, blockIdx.x, blockIdx.y, smem);
+    pw_body<PW_RS, 4, 8>(a, blockIdx.x, blockIdx.y, smem);
 }
 
+// RS = PW_RS_NARROW: a launch of narrow problems only.  These are the pointwise convolutions of the large-image stages (few
+// channels, hundreds of thousands of rows): bound by the loads in flight, and a workgroup's stage is sized by its row stride,
+// so the narrow stride doubles the workgroups a CU holds.
+template <int RS>
 __global__ __launch_bounds__(256) void pw_wgrad_group_kernel(const PwArgs* __restrict__ tab, const int* __restrict__ first, const int n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
@@ -399,10 +408,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_group_kernel(const PwArgs* __res
     lo = __builtin_amdgcn_readfirstlane(lo);
     const PwArgs a = tab[lo];          // by value: a reference into global memory would be re-read around every store
     const int local = b - first[lo];
-    pw_body(a, local % a.gx, local / a.gx, smem);
+    if constexpr (RS == PW_RS_NARROW) pw_body<RS, 1, 4>(a, local % a.gx, local / a.gx, smem);
+    else pw_body<RS, 4, 8>(a, local % a.gx, local / a.gx, smem);
 }
 
 #define PW_LDS (4 * PW_ROWS * PW_RS)
+#define PW_LDS_NARROW (4 * PW_ROWS * PW_RS_NARROW)
 
 template <int NCO, int MAXI>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
@@ -540,9 +551,9 @@ extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) 
 // ---- grouped launch ---------------------------------------------------------------------------------------------
 // Blob layout (identical bytes on host and device): header, then per kernel variant the WgradArgs of its problems and
 // the prefix table of their workgroup counts.
-#define WG_VARIANTS 6          // five tap-list kernel instances + the pointwise kernel (index 5)
-static const int kVariantNco[WG_VARIANTS] = {1, 2, 4, 1, 2, 0};
-static const int kVariantMaxi[WG_VARIANTS] = {1, 1, 1, 3, 5, 0};
+#define WG_VARIANTS 7          // five tap-list kernel instances + the pointwise kernel (index 5) + its narrow form (index 6)
+static const int kVariantNco[WG_VARIANTS] = {1, 2, 4, 1, 2, 0, -1};
+static const int kVariantMaxi[WG_VARIANTS] = {1, 1, 1, 3, 5, 0, -1};
 
 struct WgradGroupHeader {
     long long magic;
@@ -571,7 +582,7 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
         variant_of[i] = -1;
         for (int v = 0; v < WG_VARIANTS; ++v)
             if (plans[i].nco == kVariantNco[v] && plans[i].maxi == kVariantMaxi[v]) variant_of[i] = v;
-        if (plans[i].pointwise) variant_of[i] = 5;
+        if (plans[i].pointwise) variant_of[i] = (plans[i].pw.Cin <= PW_NARROW_MAX && plans[i].pw.Cout <= PW_NARROW_MAX) ? 6 : 5;
         DDPM_REQUIRE(variant_of[i] >= 0, "wgrad group: no kernel for nco=%d items/wave=%d", plans[i].nco, plans[i].maxi);
     }
     long long off = align16(sizeof(WgradGroupHeader));
@@ -580,7 +591,7 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
         for (int i = 0; i < n; ++i) cnt += variant_of[i] == v;
         h->v[v].nprob = cnt;
         h->v[v].args_off = off;
-        off = align16(off + (long long)cnt * (v == 5 ? sizeof(PwArgs) : sizeof(WgradArgs)));
+        off = align16(off + (long long)cnt * (v >= 5 ? sizeof(PwArgs) : sizeof(WgradArgs)));
         h->v[v].first_off = off;
         off = align16(off + (long long)(cnt + 1) * sizeof(int));
         WgradArgs* args = (WgradArgs*)(base + h->v[v].args_off);
@@ -590,7 +601,7 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
         long long lds = 0;
         for (int i = 0; i < n; ++i) {
             if (variant_of[i] != v) continue;
-            if (v == 5) pargs[k] = plans[i].pw; else args[k] = plans[i].a;
+            if (v >= 5) pargs[k] = plans[i].pw; else args[k] = plans[i].a;
             first[k] = blocks;
             blocks += (int)(plans[i].grid.x * plans[i].grid.y * plans[i].grid.z);
             if ((long long)plans[i].lds > lds) lds = (long long)plans[i].lds;
@@ -630,17 +641,22 @@ extern "C" int ddpm_conv_wgrad_group_launch(const void* host_blob, const void* d
             case 2: rc = launch_wgrad_group<4, 1>(h->v[v], dev, stream); break;
             case 3: rc = launch_wgrad_group<1, 3>(h->v[v], dev, stream); break;
             case 4: rc = launch_wgrad_group<2, 5>(h->v[v], dev, stream); break;
-            default: {
+            case 5: {
                 static bool attr = false;
                 if (!attr) {
-                    if (hipFuncSetAttribute((const void*)pw_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess)
+                    if (hipFuncSetAttribute((const void*)pw_wgrad_group_kernel<PW_RS>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess)
                         return ddpm_check_launch("wgrad group: raise dynamic LDS limit");
                     attr = true;
                 }
-                hipLaunchKernelGGL(pw_wgrad_group_kernel, dim3(h->v[v].total_blocks), dim3(256), PW_LDS, stream,
+                hipLaunchKernelGGL(pw_wgrad_group_kernel<PW_RS>, dim3(h->v[v].total_blocks), dim3(256), PW_LDS, stream,
                                    (const PwArgs*)(dev + h->v[v].args_off), (const int*)(dev + h->v[v].first_off), h->v[v].nprob);
                 rc = ddpm_check_launch("pw_wgrad_group");
             } break;
+            default:
+                hipLaunchKernelGGL(pw_wgrad_group_kernel<PW_RS_NARROW>, dim3(h->v[v].total_blocks), dim3(256), PW_LDS_NARROW, stream,
+                                   (const PwArgs*)(dev + h->v[v].args_off), (const int*)(dev + h->v[v].first_off), h->v[v].nprob);
+                rc = ddpm_check_launch("pw_wgrad_group (narrow)");
+                break;
         }
         if (rc) return rc;
     }

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_kernel(const GnArgs a) { GN_BY
 // in a caller-provided scratch buffer, a second launch adds the P partials of its groups / channels in a fixed order
 // (deterministic, no atomics) and applies the result to its own split.  Both launches stream at full width.
 constexpr int GS_T = 256;
+constexpr int GS_U = 4;          // rows per thread whose loads are in flight together
 
 __global__ __launch_bounds__(GS_T) void gn_fwd_split_stats_kernel(const GnArgs a) {
     __shared__ float s_red[(GS_T / 64) * 64 < 128 ? 128 : (GS_T / 64) * 64];
@@ -490,27 +491,39 @@ __device__ __forceinline__ void gn_fwd_split_apply_body(const GnArgs& a) {
     }
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
     const float bsc = (A < 0 && ACT_HAS_BETA(a.act)) ? *a.act_beta : 1.f;
-#pragma unroll 2
-    for (int r = r0 + prow; r < r1; r += pstep) {
-        const long long e = base + (long long)r * a.C;
-        const bf16x8 v = *(const bf16x8*)(a.x + e);
-        float o[8];
+    // A workgroup's strip is a few rows per thread: all of a batch's loads are issued before the first activation is evaluated
+    // (one round trip to memory per batch instead of one per row; rows past the strip's end re-read its last row and are skipped)
+    for (int rb = r0 + prow; rb < r1; rb += GS_U * pstep) {
+        bf16x8 v[GS_U], rv[GS_U];
+        unsigned m[GS_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[j] * sc[j] + sh[j], GN_ACT(A, a), bsc);
-        if (a.mask) {
-            const unsigned m = a.mask[e >> 3];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (m >> j) & 1 ? o[j] * a.mask_scale : 0.f;
+        for (int u = 0; u < GS_U; ++u) {
+            const long long e = base + (long long)min(rb + u * pstep, r1 - 1) * a.C;
+            v[u] = *(const bf16x8*)(a.x + e);
+            m[u] = a.mask ? a.mask[e >> 3] : 0xFFu;
+            if (a.res) rv[u] = *(const bf16x8*)(a.res + e);
         }
-        if (a.res) {
-            const bf16x8 rv = *(const bf16x8*)(a.res + e);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += (float)rv[j];
+        for (int u = 0; u < GS_U; ++u) {
+            const int r = rb + u * pstep;
+            if (r >= r1) break;
+            const long long e = base + (long long)r * a.C;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = act_fwd((float)v[u][j] * sc[j] + sh[j], GN_ACT(A, a), bsc);
+            if (a.mask) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (m[u] >> j) & 1 ? o[j] * a.mask_scale : 0.f;
+            }
+            if (a.res) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += (float)rv[u][j];
+            }
+            bf16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (bf16)o[j];
+            *(bf16x8*)(a.y + e) = w;
         }
-        bf16x8 w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = (bf16)o[j];
-        *(bf16x8*)(a.y + e) = w;
     }
 }
 
@@ -538,21 +551,26 @@ __device__ __forceinline__ void gn_bwd_lane_init(const GnArgs& a, int n, int c, 
 }
 // with_ab: also adds this vector's terms of the activation scalar's gradient to ab (an array by reference: a pointer that
 // may be null would put the caller's array in scratch memory)
+struct GnBwdIn { bf16x8 xv, dv; unsigned m; };
+__device__ __forceinline__ GnBwdIn gn_bwd_load(const GnArgs& a, long long e) {
+    GnBwdIn q;
+    q.xv = *(const bf16x8*)(a.x + e); q.dv = *(const bf16x8*)(a.dy + e);
+    q.m = a.mask ? a.mask[e >> 3] : 0xFFu;
+    return q;
+}
 template <int A>
-__device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, long long e, float (&g)[8], float (&xh)[8], float (&xf)[8],
+__device__ __forceinline__ void gn_bwd_gx(const GnArgs& a, const GnBwdLane& L, const GnBwdIn& q, float (&g)[8], float (&xh)[8], float (&xf)[8],
                                           float (&ab)[8], bool with_ab) {
-    const bf16x8 xv = *(const bf16x8*)(a.x + e), dv = *(const bf16x8*)(a.dy + e);
-    const unsigned m = a.mask ? a.mask[e >> 3] : 0xFFu;
     const float ms = a.mask ? a.mask_scale : 1.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        xf[j] = (float)xv[j];
+        xf[j] = (float)q.xv[j];
         xh[j] = (xf[j] - L.mean[j]) * L.rstd[j];
         const float z = xh[j] * L.ga[j] + L.be[j];
-        const float gg = (float)dv[j] * act_bwd(z, GN_ACT(A, a), L.bsc) * ms;
-        g[j] = (m >> j) & 1 ? gg : 0.f;
+        const float gg = (float)q.dv[j] * act_bwd(z, GN_ACT(A, a), L.bsc) * ms;
+        g[j] = (q.m >> j) & 1 ? gg : 0.f;
         if constexpr (A < 0)
-            if (with_ab) ab[j] += (m >> j) & 1 ? (float)dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
+            if (with_ab) ab[j] += (q.m >> j) & 1 ? (float)q.dv[j] * act_dbeta(z, a.act, L.bsc) * ms : 0.f;
     }
 }
 
@@ -578,12 +596,20 @@ __device__ __forceinline__ void gn_bwd_split_sums_body(const GnArgs& a) {
     const bool hb = A < 0 && ACT_HAS_BETA(a.act);
     const int R = gn_bwd_rows(a.act);
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
-#pragma unroll 2
-    for (int r = r0 + prow; r < r1; r += pstep) {
-        float g[8], xh[8], xf[8];
-        gn_bwd_gx<A>(a, L, base + (long long)r * a.C, g, xh, xf, ab, hb);
+    // (a batch's loads are all in flight before its first row is evaluated; rows past the strip's end re-read its last row and
+    // are skipped)
+    for (int rb = r0 + prow; rb < r1; rb += GS_U * pstep) {
+        GnBwdIn in[GS_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
+        for (int u = 0; u < GS_U; ++u) in[u] = gn_bwd_load(a, base + (long long)min(rb + u * pstep, r1 - 1) * a.C);
+#pragma unroll
+        for (int u = 0; u < GS_U; ++u) {
+            if (rb + u * pstep >= r1) break;
+            float g[8], xh[8], xf[8];
+            gn_bwd_gx<A>(a, L, in[u], g, xh, xf, ab, hb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
+        }
     }
     block_reduce_cols<GS_T>(a1, vps, s_red, tid);
     block_reduce_cols<GS_T>(a2, vps, s_red, tid);
@@ -661,15 +687,21 @@ __device__ __forceinline__ void gn_bwd_split_apply_body(const GnArgs& a) {
         S1[j] = a.G > 0 ? s_s1[g] : 0.f; S2[j] = a.G > 0 ? s_s2[g] : 0.f;
     }
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
-#pragma unroll 2
-    for (int r = r0 + prow; r < r1; r += pstep) {
-        const long long e = base + (long long)r * a.C;
-        float g[8], xh[8], xf[8], none[8];
-        gn_bwd_gx<A>(a, L, e, g, xh, xf, none, false);
-        bf16x8 w;
+    for (int rb = r0 + prow; rb < r1; rb += GS_U * pstep) {
+        GnBwdIn in[GS_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = (bf16)(L.rstd[j] * (L.ga[j] * g[j] - (S1[j] + xh[j] * S2[j])));
-        *(bf16x8*)(a.y + e) = w;
+        for (int u = 0; u < GS_U; ++u) in[u] = gn_bwd_load(a, base + (long long)min(rb + u * pstep, r1 - 1) * a.C);
+#pragma unroll
+        for (int u = 0; u < GS_U; ++u) {
+            const int r = rb + u * pstep;
+            if (r >= r1) break;
+            float g[8], xh[8], xf[8], none[8];
+            gn_bwd_gx<A>(a, L, in[u], g, xh, xf, none, false);
+            bf16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (bf16)(L.rstd[j] * (L.ga[j] * g[j] - (S1[j] + xh[j] * S2[j])));
+            *(bf16x8*)(a.y + base + (long long)r * a.C) = w;
+        }
     }
 }
 

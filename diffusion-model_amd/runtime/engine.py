@@ -629,7 +629,10 @@ class UNetEngine:
                     draw = wide
                 nb = ops.dwconv3x3_wgrad_blocks(*xin.v.shape)
                 buf, off = part_alloc(nb * 10 * cch)
-                ops.dwconv3x3_wgrad(xin.v, draw, buf)
+                if self.group_wgrad:     # leaf work: with the phase's other weight gradients, beside the next phase's chain
+                    late_wgrad.append(lambda: ops.dwconv3x3_wgrad(xin.v, draw, buf))
+                else:
+                    ops.dwconv3x3_wgrad(xin.v, draw, buf)
                 part_entries.append((off, G.offset(name + ".weight"), nb, 10 * cch, 9 * cch))
                 part_entries.append((off + 9 * cch, G.offset(name + ".bias"), nb, 10 * cch, cch))
                 assert xin.g is None
