@@ -596,19 +596,25 @@ __device__ __forceinline__ void gn_bwd_split_sums_body(const GnArgs& a) {
     const bool hb = A < 0 && ACT_HAS_BETA(a.act);
     const int R = gn_bwd_rows(a.act);
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
-    // (a batch's loads are all in flight before its first row is evaluated; rows past the strip's end re-read its last row and
-    // are skipped)
-    for (int rb = r0 + prow; rb < r1; rb += GS_U * pstep) {
-        GnBwdIn in[GS_U];
+    // g = dy * mask * act'(z) is evaluated once per element, here: it goes to the result tensor in bf16 and the second launch
+    // turns it into the input gradient in place (the activation's derivative is most of either launch's arithmetic).
+    // A batch's loads are all in flight before its first row is evaluated; rows past the strip's end re-read its last row and
+    // are skipped.
+    constexpr int UB = 2;
+    for (int rb = r0 + prow; rb < r1; rb += UB * pstep) {
+        GnBwdIn in[UB];
 #pragma unroll
-        for (int u = 0; u < GS_U; ++u) in[u] = gn_bwd_load(a, base + (long long)min(rb + u * pstep, r1 - 1) * a.C);
+        for (int u = 0; u < UB; ++u) in[u] = gn_bwd_load(a, base + (long long)min(rb + u * pstep, r1 - 1) * a.C);
 #pragma unroll
-        for (int u = 0; u < GS_U; ++u) {
-            if (rb + u * pstep >= r1) break;
+        for (int u = 0; u < UB; ++u) {
+            const int r = rb + u * pstep;
+            if (r >= r1) break;
             float g[8], xh[8], xf[8];
             gn_bwd_gx<A>(a, L, in[u], g, xh, xf, ab, hb);
+            bf16x8 gv;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
+            for (int j = 0; j < 8; ++j) { gv[j] = (bf16)g[j]; a1[j] += g[j]; a2[j] += g[j] * xh[j]; sx[j] += xf[j]; }
+            *(bf16x8*)(a.y + base + (long long)r * a.C) = gv;
         }
     }
     block_reduce_cols<GS_T>(a1, vps, s_red, tid);
@@ -678,34 +684,40 @@ __device__ __forceinline__ void gn_bwd_split_apply_body(const GnArgs& a) {
         }
         a.part[((long long)n * 3 + 2) * a.C + c] = dbias;
     }
-    GnBwdLane L;
-    gn_bwd_lane_init(a, n, c0 + cv * 8, L);
-    float S1[8], S2[8];
+    // dx = rstd (gamma g - S1 - xhat S2) from x and the g the first launch left in the result tensor, in place; per channel:
+    // dx = k1 g - (k0 + k2 x) with k1 = rstd gamma, k2 = rstd^2 S2, k0 = rstd (S1 - mean rstd S2)
+    float k0[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int g = (cv * 8 + j) / cpg;
-        S1[j] = a.G > 0 ? s_s1[g] : 0.f; S2[j] = a.G > 0 ? s_s2[g] : 0.f;
+        const int cl = cv * 8 + j, g = cl / cpg;
+        float mean = 0.f, rstd = 1.f, ga = 1.f, s1 = 0.f, s2 = 0.f;
+        if (a.G > 0) {
+            mean = a.stats[((long long)n * a.G + c0 / cpg + g) * 2]; rstd = a.stats[((long long)n * a.G + c0 / cpg + g) * 2 + 1];
+            ga = a.gamma[c0 + cl]; s1 = s_s1[g]; s2 = s_s2[g];
+        }
+        k1[j] = rstd * ga; k2[j] = rstd * rstd * s2; k0[j] = rstd * (s1 - mean * rstd * s2);
     }
     const int r0 = p * a.rows_per_split, r1 = min(a.HW, r0 + a.rows_per_split);
     for (int rb = r0 + prow; rb < r1; rb += GS_U * pstep) {
-        GnBwdIn in[GS_U];
+        bf16x8 xv[GS_U], gv[GS_U];
 #pragma unroll
-        for (int u = 0; u < GS_U; ++u) in[u] = gn_bwd_load(a, base + (long long)min(rb + u * pstep, r1 - 1) * a.C);
+        for (int u = 0; u < GS_U; ++u) {
+            const long long e = base + (long long)min(rb + u * pstep, r1 - 1) * a.C;
+            xv[u] = *(const bf16x8*)(a.x + e); gv[u] = *(const bf16x8*)(a.y + e);
+        }
 #pragma unroll
         for (int u = 0; u < GS_U; ++u) {
             const int r = rb + u * pstep;
             if (r >= r1) break;
-            float g[8], xh[8], xf[8], none[8];
-            gn_bwd_gx<A>(a, L, in[u], g, xh, xf, none, false);
             bf16x8 w;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = (bf16)(L.rstd[j] * (L.ga[j] * g[j] - (S1[j] + xh[j] * S2[j])));
+            for (int j = 0; j < 8; ++j) w[j] = (bf16)(k1[j] * (float)gv[u][j] - (k0[j] + k2[j] * (float)xv[u][j]));
             *(bf16x8*)(a.y + base + (long long)r * a.C) = w;
         }
     }
 }
 
-__global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a) { GN_BY_ACT(gn_bwd_split_apply_body, GS_T); }
+__global__ __launch_bounds__(GS_T) void gn_bwd_split_apply_kernel(const GnArgs a) { gn_bwd_split_apply_body<GS_T, 0>(a); }
 
 // splits of a slab's pixels on the split path (0 = the slab is small enough for one workgroup)
 static int gn_splits(const GnArgs& a) {
@@ -853,6 +865,7 @@ extern "C" int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream_
     if (int rc = gn_prepare(a, d, "gn_backward")) return rc;
     DDPM_REQUIRE(d->dy, "gn_backward: null dy");
     DDPM_REQUIRE(a.part, "gn_backward: partial-sum workspace required");
+    DDPM_REQUIRE((const void*)d->y != d->x, "gn_backward: the result may overwrite dy, not x (large images keep an intermediate in it while x is still read)");
     DDPM_REQUIRE(!ACT_HAS_BETA(a.act) || a.dbeta_part, "gn_backward: swish / hardswish need the [N][C] workspace of the scalar's gradient (dbeta_part)");
     if (gn_use_split(a, d, true)) {
         const int units = a.N * (a.C / a.SC) * a.P;

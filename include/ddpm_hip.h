@@ -252,7 +252,8 @@ typedef struct ddpm_gn_desc {
 /* y = [res +] mask * act(GroupNorm_G(x) * gamma + beta)     torch.nn.GroupNorm + activation sites:
  * constituent_blocks.py:68-73,83-88,169-174,182-187; conv_block.py:67-72,90-95,110-114; unets.py:80-85,162-167 */
 int ddpm_gn_act_forward(const ddpm_gn_desc* d, ddpm_stream_t stream);
-/* dx and the per-image partial sums of dgamma, dbeta, dbias of the above (no atomics: deterministic). */
+/* dx and the per-image partial sums of dgamma, dbeta, dbias of the above (no atomics: deterministic).  y (= dx) may be the
+ * same tensor as dy, never the same as x. */
 int ddpm_gn_act_backward(const ddpm_gn_desc* d, ddpm_stream_t stream);
 
 /* GroupNorm statistics from the producer's partial sums, as what a consumer needs to normalise on load: stat_part = fp32

@@ -670,16 +670,51 @@ def test_pointwise_streaming_kernel_with_input_dropout(dev, n, ci, co, h, act):
     assert_rel(nchw(got), F.conv2d(x_eff, w, b), 1e-2)
 
 
+@pytest.mark.parametrize("n,ci,co,h,with_mask,with_res", [(2, 64, 32, 64, True, True), (3, 32, 64, 32, True, False), (1, 128, 64, 16, False, True),
+                                                           (2, 64, 64, 32, True, True)])
+def test_pointwise_streaming_kernel_masked_and_added_result(dev, n, ci, co, h, with_mask, with_res):
+    """the data-gradient form of the block's expansion (conv_block.py:57-76 of the reference, backward): the result's dropout mask and
+    the tensor added last.  The general kernel applies both to the bf16-rounded product, and so does this one: the two differ by
+    the dot product's rounding only; and against torch fp32."""
+    lib = hip.lib()
+    x = r16(hash_normal((n, ci, h, h), 391))
+    w = r16(hash_normal((co, ci, 1, 1), 392) * (1.0 / ci) ** 0.5)
+    res = r16(hash_normal((n, co, h, h), 393)) if with_res else None
+    keep = hash_uniform((n, h, h, co), 394) < 0.8
+    kb = (keep.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).to(dev) if with_mask else None
+    xd, wp = nhwc(x, dev), pack.pack_fwd(hip.CONV_1X1, w.to(dev))
+    kw = dict(res=None if res is None else nhwc(res, dev), out_mask=kb, out_scale=1 / 0.8 if with_mask else 1.0)
+    prev = lib.ddpm_conv_pw_stream_mode(1)
+    try:
+        got = ops.conv_forward(hip.CONV_1X1, xd, wp, None, co, **kw)
+        assert lib.ddpm_conv_last_kernel() == 6
+        lib.ddpm_conv_pw_stream_mode(-1)
+        ref = ops.conv_forward(hip.CONV_1X1, xd, wp, None, co, **kw)
+        assert lib.ddpm_conv_last_kernel() != 6
+    finally:
+        lib.ddpm_conv_pw_stream_mode(prev)
+    assert_rel(got.float().cpu(), ref.float().cpu(), 8e-3)
+    want = F.conv2d(x, w)
+    if with_mask:
+        want = want * keep.permute(0, 3, 1, 2) / 0.8
+        if not with_res:
+            assert torch.equal((got == 0).cpu() | keep, torch.ones_like(keep))      # dropped elements are exact zeros
+    if with_res:
+        want = want + res
+    assert_rel(nchw(got), want, 1e-2)
+
+
 def test_pointwise_streaming_kernel_declines_what_it_does_not_cover(dev):
     """other shapes, fused epilogues and small problems stay on the other kernels (mode 0 = by size)"""
     lib = hip.lib()
     prev = lib.ddpm_conv_pw_stream_mode(1)
     try:
-        for ci, co, h, kw in ((256, 64, 16, {}), (128, 128, 16, {}), (64, 32, 10, {}), (64, 32, 16, {"act": hip.ACT["gelu"]}), (64, 32, 16, {"res": True})):
+        for ci, co, h, kw in ((256, 64, 16, {}), (128, 128, 16, {}), (64, 32, 10, {}), (64, 32, 16, {"act": hip.ACT["gelu"]}),
+                              (64, 32, 16, {"sum_out": True})):
             x = torch.zeros(2, h, h, ci, device=dev, dtype=torch.bfloat16)
             w = pack.pack_fwd(hip.CONV_1X1, torch.zeros(co, ci, 1, 1, device=dev))
-            if kw.get("res"):
-                kw = {"res": torch.zeros(2, h, h, co, device=dev, dtype=torch.bfloat16)}
+            if kw.get("sum_out"):
+                kw = {"sum_out": torch.zeros(2, co, device=dev)}
             ops.conv_forward(hip.CONV_1X1, x, w, None, co, **kw)
             assert lib.ddpm_conv_last_kernel() != 6, (ci, co, h, kw)
         lib.ddpm_conv_pw_stream_mode(0)
