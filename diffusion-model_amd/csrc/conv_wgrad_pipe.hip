@@ -17,6 +17,8 @@
 #include "ddpm_hip.h"
 
 int ddpm_conv_pipe_mode_now();            // conv_pipe.hip: 0 by problem size, 1 wherever the shape allows, -1 never
+int ddpm_conv_wgrad_c32_splits(const ddpm_wgrad_desc* d);                     // conv_wgrad_c32.hip: the thin convolutions of the image ends
+int ddpm_conv_wgrad_c32_try(const ddpm_wgrad_desc* d, hipStream_t stream);
 
 namespace {
 
@@ -282,12 +284,14 @@ bool plan(const ddpm_wgrad_desc* d, WpArgs& a) {
 
 // Number of `part` rows the pipelined kernel writes for this problem, or 0 when it does not take it.
 extern "C" int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d) {
+    if (const int s = ddpm_conv_wgrad_c32_splits(d)) return s;
     WpArgs a;
     return plan(d, a) ? a.splits : 0;
 }
 
 // Returns 1 when the problem was launched here, 0 when the caller should use another kernel, < 0 on error.
 int ddpm_conv_wgrad_pipe_try(const ddpm_wgrad_desc* d, hipStream_t stream) {
+    if (const int rc = ddpm_conv_wgrad_c32_try(d, stream)) return rc;
     WpArgs a;
     if (!plan(d, a)) return 0;
     a.x = (const bf16*)d->in0; a.x1 = (const bf16*)d->in1; a.dy = (const bf16*)d->dy; a.dw = d->dw; a.part = d->part;

@@ -344,9 +344,11 @@ int64_t ddpm_conv_wgrad_group_bytes(int n);
 int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, void* host_blob, int64_t bytes);
 int ddpm_conv_wgrad_group_launch(const void* host_blob, const void* dev_blob, ddpm_stream_t stream);
 int ddpm_conv_wgrad_splits(const ddpm_wgrad_desc* d);   /* rows of `part` for this problem (shape fields only are read); -1 on error */
-/* Rows of `part` when a standalone ddpm_conv_wgrad call (tiles_per_split = 0) takes this problem to the pipelined kernel for
- * deep wide 3x3 stride-1 convolutions at large batch (conv_wgrad_pipe.hip), 0 when it does not: a caller that groups its
- * problems can launch these on their own.  (The reference leaves the choice of kernel to torch: no counterpart.) */
+/* Rows of `part` when a standalone ddpm_conv_wgrad call (tiles_per_split = 0) takes this problem to one of the dedicated
+ * kernels - the pipelined one for deep wide 3x3 stride-1 convolutions at large batch (conv_wgrad_pipe.hip) or the one for the
+ * thin 3x3 convolutions at the image ends, 16 / 32 stored channels on 32 / 64 / 128-pixel-wide images (conv_wgrad_c32.hip) -,
+ * 0 when it does not: a caller that groups its problems can launch these on their own.  (The reference leaves the choice of
+ * kernel to torch: no counterpart.) */
 int ddpm_conv_wgrad_pipe_splits(const ddpm_wgrad_desc* d);
 
 /* db[C] += column sums of an NHWC bf16 tensor [rows][cs] (first C channels); fp32 atomics. */

@@ -220,6 +220,46 @@ def test_conv_wgrad_pipelined_kernel(dev, n, ci, co, w_):
     assert_rel(dwk.cpu(), old.cpu(), 1e-4)                           # same bf16 products, fp32 sums in another order
 
 
+@pytest.mark.parametrize("n,ci,co,h,w_,with_add", [(3, 16, 32, 32, 32, False), (2, 32, 32, 64, 64, True), (5, 32, 3, 32, 32, False),
+                                                    (1, 32, 32, 128, 128, False), (70, 32, 32, 32, 32, True), (2, 16, 32, 16, 64, False),
+                                                    (1, 32, 1, 8, 128, False)])
+def test_conv_wgrad_image_end_kernel(dev, n, ci, co, h, w_, with_add):
+    """The weight-gradient kernel of the thin 3x3 convolutions at the image ends (stem: 16 stored input channels; first-stage and
+    feature convolutions 32 -> 32, with the time-embedding add of the forward loader; head: 3 or 1 of 16 stored output channels;
+    unets.py:78-85,160-167 of the reference), forced onto small problems: atomics into dw and per-workgroup partial blocks,
+    against torch fp32 on the same bf16 operands and against the tap-list kernel.  (70 images: more bands than workgroups.)"""
+    w = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    x = r16(hash_normal((n, ci, h, w_), 3))
+    temb = hash_normal((n, ci), 5) if with_add else None
+    xin = x if temb is None else r16(x + temb[:, :, None, None])
+    ref = F.conv2d(xin, w, None, padding=1)
+    gy = r16(hash_normal(tuple(ref.shape), 4))
+    (gw,) = torch.autograd.grad(ref, w, gy)
+    xd, gd = nhwc(x, dev), nhwc(gy, dev, (co + 15) // 16 * 16)
+    kw = {} if temb is None else {"in_add": temb.to(dev)}
+    old = torch.zeros(9, co, ci, device=dev)
+    prev = hip.lib().ddpm_conv_pipe_mode(-1)
+    try:
+        assert ops.conv_wgrad_pipe_splits(hip.CONV_3X3_S1, xd, gd, co, **kw) == 0
+        ops.conv_wgrad(hip.CONV_3X3_S1, xd, gd, co, old, **kw)
+        hip.lib().ddpm_conv_pipe_mode(1)
+        splits = ops.conv_wgrad_pipe_splits(hip.CONV_3X3_S1, xd, gd, co, **kw)
+        assert splits == min(256, n * h * w_ // 256), splits
+        assert ops.conv_wgrad_splits(hip.CONV_3X3_S1, xd, gd, co) == splits
+        dwk = torch.zeros(9, co, ci, device=dev)
+        ops.conv_wgrad(hip.CONV_3X3_S1, xd, gd, co, dwk, **kw)
+        part = torch.full((splits, 9, co, ci), float("nan"), device=dev)
+        ops.conv_wgrad(hip.CONV_3X3_S1, xd, gd, co, None, part=part, **kw)
+        hip.lib().ddpm_conv_pipe_mode(0)
+        small = n * h * w_ < 65536
+        assert (ops.conv_wgrad_pipe_splits(hip.CONV_3X3_S1, xd, gd, co, **kw) == 0) == small       # by size: one band per CU and more
+    finally:
+        hip.lib().ddpm_conv_pipe_mode(prev)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, dwk.cpu(), co, ci), gw, 5e-3)
+    assert_rel(unpack_dw(hip.CONV_3X3_S1, part.sum(0).cpu(), co, ci), gw, 5e-3)
+    assert_rel(dwk.cpu(), old.cpu(), 1e-4)                           # same bf16 products, fp32 sums in another order
+
+
 def test_conv_wgrad_pipelined_kernel_two_sources(dev):
     """concatenated input (two NHWC sources): an input-channel block of the pipelined kernel reads from one of them"""
     n, c0, c1, co, h = 24, 64, 128, 128, 8
