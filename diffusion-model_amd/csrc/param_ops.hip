@@ -119,15 +119,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ void bump_step_kernel(long long* step) { *step += 1; }
 
-extern "C" int ddpm_adam_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
-                              float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
-                              int64_t* step, ddpm_stream_t stream_) {
+extern "C" int ddpm_adam_step_range(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                                    int64_t* step, int bump, ddpm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DDPM_REQUIRE(p && g && m && v && step && n > 0 && n % 4 == 0, "adam: bad arguments (n must be a multiple of 4)");
     long long gx = (n / 4 + 255) / 256;
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, stream, p, g, m, v, ema, (long long)n, lr_dev, lr, beta1, beta2, eps,
                        weight_decay, ema_decay, grad_scale, (long long*)step);
-    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, stream, (long long*)step);
+    if (bump) hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, stream, (long long*)step);
     return ddpm_check_launch("adam");
+}
+
+extern "C" int ddpm_adam_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                              int64_t* step, ddpm_stream_t stream) {
+    return ddpm_adam_step_range(p, g, m, v, ema, n, lr_dev, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale, step, 1, stream);
 }

@@ -133,6 +133,34 @@ class FusedAdam(torch.optim.Optimizer):
         bump_weight_epoch()               # the update happened outside torch's view: invalidate cached weight copies
         return loss
 
+    @torch.no_grad()
+    def step_ranges(self, ranges, last: bool, grad_scale: float = 1.0) -> None:
+        """One optimizer step taken in pieces: the update of the element ranges [lo, hi) of the flat parameter buffer (multiples
+        of 4, e.g. GradStore.unpack_phase / unpack_where ranges), for a driver whose gradients become final in parts.  The
+        update is element-wise, so the pieces of one step together give exactly step()'s numbers; the pieces must be
+        disjoint, cover every parameter once per step, and only the last call says last=True (it advances the step count)."""
+        if self._flat is None:
+            self._flatten()
+        ps = self._params()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        g = self._flat_grad(ps)
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        ranges = list(ranges)
+        for i, (lo, hi) in enumerate(ranges):
+            if not (0 <= lo < hi <= self._total and lo % 4 == 0 and (hi - lo) % 4 == 0):
+                raise ValueError(f"FusedAdam.step_ranges: bad range [{lo}, {hi}) of {self._total}")
+            at = lambda t: 0 if t is None else t.data_ptr() + 4 * lo
+            hip.call("ddpm_adam_step_range", at(self._flat), at(g), at(self._m), at(self._v), at(self._ema), hi - lo,
+                     hip.ptr(self._lr), float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]),
+                     float(self.ema_decay if self.ema_decay is not None else 0.0), float(grad_scale), hip.ptr(self._step),
+                     int(last and i == len(ranges) - 1), hip.stream())
+        if last:
+            if not ranges:
+                raise ValueError("FusedAdam.step_ranges: the last piece of a step cannot be empty")
+            bump_weight_epoch()
+
 
     # ---- checkpoint interchange ----------------------------------------------------------------------------------------
     # The reference saves optimizer.state_dict() of torch.optim.Adam into its checkpoints (base_trainer.py:118-130,285-294

@@ -181,6 +181,7 @@ _PROTOS = {
     "ddpm_sir_workgroups": ([_i, _i], _i),
     "ddpm_sir_backward": ([_vp, _vp], _i),
     "ddpm_adam_step": ([_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _vp, _vp], _i),
+    "ddpm_adam_step_range": ([_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _f, _vp, _i, _vp], _i),
     "ddpm_conv_wgrad": ([C.POINTER(WgradDesc), _vp], _i),
     "ddpm_colsum": ([_vp, _vp, _i64, _i, _i, _vp], _i),
     "ddpm_spatial_sum": ([_vp, _vp, _i, _i, _i, _vp], _i),

@@ -89,7 +89,9 @@ class WeightCache:
 
     def _build(self, params: Dict[str, Tensor], device) -> None:
         entries: List[hip.RemapEntry] = []
+        owner: List[str] = []                         # layer name of every entry (refresh_where)
         for name, kind in self.convs.items():
+            owner += [name, name]
             w = lookup(params, self.aliases, name + ".weight")
             co, ci, kk = conv_dims(kind, w)
             cow, cip, ciw, cop = _ru(co, 32), _ru(ci, 16), _ru(ci, 32), _ru(co, 16)
@@ -105,6 +107,7 @@ class WeightCache:
                 entries.append(_entry(self.fwd[name].data_ptr(), w.data_ptr(), kk, cow, cip, co, ci, ci * kk, kk, ident, True))
                 entries.append(_entry(self.dgrad[name].data_ptr(), w.data_ptr(), kk, ciw, cop, ci, co, kk, ci * kk, flip, True))
         for name in self.dwconvs:
+            owner += [name, name]
             w = params[name + ".weight"]
             c = w.shape[0]
             if name not in self.dw:
@@ -113,17 +116,36 @@ class WeightCache:
             entries.append(_entry(self.dw[name].data_ptr(), w.data_ptr(), 9, 1, c, 1, c, 0, 9, list(range(9)), False))
             entries.append(_entry(self.dw_flip[name].data_ptr(), w.data_ptr(), 9, 1, c, 1, c, 0, 9, [8 - s for s in range(9)], False))
         self._table, self._chunks, self._n = _to_device(entries, device)
+        self._entries, self._owner, self._subsets = entries, owner, {}
 
-    def refresh(self, params: Dict[str, Tensor], device, force: bool = False) -> None:
+    def _state(self, params: Dict[str, Tensor]):
         names = [n + ".weight" for n in self.convs] + [n + ".weight" for n in self.dwconvs]
         ws = [lookup(params, self.aliases, n) for n in names]
-        ptrs = tuple(w.data_ptr() for w in ws)
-        vers = (_WEIGHT_EPOCH[0],) + tuple(w._version for w in ws)
+        return tuple(w.data_ptr() for w in ws), (_WEIGHT_EPOCH[0],) + tuple(w._version for w in ws)
+
+    def refresh(self, params: Dict[str, Tensor], device, force: bool = False) -> None:
+        ptrs, vers = self._state(params)
         if ptrs != self._ptrs:
             self._build(params, device)
             self._ptrs, self._vers = ptrs, ()
         if force or vers != self._vers:
             hip.call("ddpm_remap", hip.ptr(self._table), hip.ptr(self._chunks), self._n, 1, hip.stream())
+            self._vers = vers
+
+    def refresh_where(self, tag: str, keep, params: Dict[str, Tensor], device, done: bool) -> None:
+        """refresh() for the layers whose name passes keep(name) (cached under `tag`), for a driver that updates the parameters
+        in pieces: one launch over that subset.  done=True on the piece that completes the set: the copies then count as
+        current for the parameters' present state."""
+        ptrs, vers = self._state(params)
+        if ptrs != self._ptrs:
+            raise RuntimeError("WeightCache.refresh_where: the parameters moved since the copies were laid out; call refresh() first")
+        if tag not in self._subsets:
+            sub = [e for e, n in zip(self._entries, self._owner) if keep(n)]
+            self._subsets[tag] = _to_device(sub, device) if sub else None
+        t = self._subsets[tag]
+        if t is not None:
+            hip.call("ddpm_remap", hip.ptr(t[0]), hip.ptr(t[1]), t[2], 1, hip.stream())
+        if done:
             self._vers = vers
 
 

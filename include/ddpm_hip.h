@@ -387,6 +387,13 @@ int ddpm_remap_chunk_elems(void);
 int ddpm_adam_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int64_t* step,
                    ddpm_stream_t stream);
+/* The same step on a range of the flat buffers (all pointers moved to the range's start, n = its length), for a driver that
+ * updates a network's parameters in pieces as their gradients become final (the reference calls optimizer.step() once,
+ * base_trainer.py:229: element-wise, so the pieces give the same numbers).  Every piece of one step reads the same *step;
+ * only the call with bump != 0 (the step's last) increments it. */
+int ddpm_adam_step_range(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* lr_dev, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, int64_t* step,
+                         int bump, ddpm_stream_t stream);
 
 /* One SeparableInvertResidual block (conv_block.py:57-136: dropout -> 1x1 expansion -> GroupNorm -> act -> dropout ->
  * depthwise 3x3 -> GroupNorm -> act -> dropout -> 1x1 projection -> GroupNorm -> + input) as a single launch with the

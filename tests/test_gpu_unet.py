@@ -330,6 +330,38 @@ def test_fused_adam_matches_torch_adam(dev):
     assert torch.equal(mb(x0, t), mc(x0, t))
 
 
+def test_fused_adam_step_in_pieces(dev):
+    """FusedAdam.step_ranges: one optimizer step taken as updates of disjoint element ranges (what the pipelined driver does as the
+    gradients of the decoder, the deep encoder stages and the rest become final) gives step()'s numbers bit for bit - parameters,
+    moments, EMA and the step count that the bias correction reads - over three steps."""
+    from dm_amd.optimizer import FusedAdam
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(32, 16, 3, 3), (32,), (7, 5), (128, 64), (3,), (64, 32, 1, 1)]
+    pa = [torch.nn.Parameter(torch.randn(sh, generator=gen).to(dev)) for sh in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdam(pa, lr=3e-3, weight_decay=1e-2, ema_decay=0.9)
+    ob = FusedAdam(pb, lr=3e-3, weight_decay=1e-2, ema_decay=0.9)
+    for it in range(3):
+        grads = [torch.randn(sh, generator=gen).to(dev) for sh in shapes]
+        for p, g in zip(pa, grads):
+            p.grad = g.clone()
+        for p, g in zip(pb, grads):
+            p.grad = g.clone()
+        oa.step()
+        if ob._flat is None:
+            ob._flatten()
+        offs, total = ob._offs, ob._total
+        cuts = [0, offs[2], offs[4], total]                    # three pieces, taken out of order; the last one advances the count
+        ob.step_ranges([(cuts[1], cuts[2])], last=False)
+        ob.step_ranges([(cuts[2], cuts[3]), (cuts[0], cuts[1])], last=True)
+        assert int(ob._step.item()) == int(oa._step.item()) == it + 1
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.detach(), b.detach())
+    assert torch.equal(oa._m, ob._m) and torch.equal(oa._v, ob._v) and torch.equal(oa._ema, ob._ema)
+    with pytest.raises(ValueError):
+        ob.step_ranges([(2, 6)], last=False)
+
+
 def test_graphed_train_step_with_gradient_hook(dev):
     """The data-parallel step: graph (forward+backward) -> eager gradient hook -> graph (optimizer).  On one GPU the
     hook is (a) a one-rank RCCL all-reduce through GradReducer's collective path, which must leave training intact, and

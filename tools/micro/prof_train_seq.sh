@@ -9,7 +9,7 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/pts/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adam_kernel')]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('bump_step_kernel')]      # one per step, right after its last Adam launch
 a, b = idx[-3] + 1, idx[-2] + 1
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
