@@ -48,7 +48,7 @@ FAMILIES = {
     "sir_bwd_kernel": ("sir_bwd", "main", ("sir_bwd_kernel",)),
     "sir_bwd_big_kernel": ("sir_bwd", "main", ("sir_bwd_big_kernel",)),
     "conv_wgrad_group_kernel": ("conv_wgrad_group", "side", ("conv_wgrad_group_kernel", "pw_wgrad_group_kernel")),
-    "conv_wgrad_kernel": ("conv_wgrad", "side", ("conv_wgrad_kernel", "pw_wgrad_kernel")),
+    "conv_wgrad_kernel": ("conv_wgrad", "side", ("conv_wgrad_kernel", "pw_wgrad_kernel", "conv_wgrad_pipe_kernel", "conv_wgrad_c32_kernel")),
     "conv_thin_kernel": ("conv_thin", "main", ("conv_thin_in_kernel", "conv_thin_out_kernel", "conv_thin_out_mfma_kernel", "conv3x3_c32_kernel")),
     "embed_bwd_kernel": ("embed_bwd", "side", ("embed_bwd_kernel",)),
     "dwconv3x3_wgrad_kernel": ("dwconv3x3_wgrad", "side", ("dwconv3x3_wgrad_kernel",)),
@@ -62,8 +62,9 @@ def _family(name: str):
 
 def _pmc_bytes_per_step(measured: Dict, kernels) -> float:
     """HBM bytes one step moves in the given device kernels, from the counter-pass file: per kernel name it holds the bytes per
-    launch and the launches sampled; the optimizer kernel runs once per step, so its launch count is the number of steps."""
-    steps = measured.get("adam_kernel", {}).get("launches_sampled", 0)
+    launch and the launches sampled; the step counter's kernel runs once per step (the optimizer kernel may run in pieces), so its
+    launch count is the number of steps."""
+    steps = measured.get("bump_step_kernel", measured.get("adam_kernel", {})).get("launches_sampled", 0)
     if not steps:
         return None
     tot, seen = 0.0, False

@@ -1,10 +1,11 @@
-"""Summarise a rocprofv3 --kernel-trace CSV: for the last full training step (between two adam_kernel launches) print,
+"""Summarise a rocprofv3 --kernel-trace CSV: for the last full training step (between two bump_step_kernel launches: one per
+step, right after its last Adam launch) print,
 per queue, busy time and gaps, and list the kernels of the less busy queue with their offsets.
 python tools/micro/timeline.py <kernel_trace.csv>"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adams = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+adams = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("bump_step_kernel")]
 a, b = adams[-2], adams[-1]
 step = rows[a + 1:b + 1]
 t0 = int(rows[a]["End_Timestamp"])

@@ -27,7 +27,7 @@ import sys
 
 
 def family(name: str) -> str:
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"_Z(\d+)", name)
     if m:
         n = int(m.group(1))
@@ -37,7 +37,7 @@ def family(name: str) -> str:
 
 def instance(name: str) -> str:
     """template instance without the argument list: conv_img_kernel<8, 1, 1, 1, 512, 0>"""
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     depth = 0
     for i, ch in enumerate(name):
         depth += ch == "<"
