@@ -274,10 +274,11 @@ struct PwArgs {
 // (8 covers 64 rows of 128 + 128 channels, 4 covers 64 + 64).  The narrow form needs a third of the registers.
 template <int RS, int NACC, int NSLOT>
 __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int by, char* smem) {
+    constexpr int CB = RS == PW_RS_NARROW ? PW_NARROW_MAX : 128;      // channels of either operand per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cb = by / a.nib, ib = by - cb * a.nib;
-    const int co0 = cb * 128, ci0 = ib * 128;
-    const int cow = min(128, ((a.Cout - co0) + 31) & ~31), ciw = min(128, a.Cin - ci0);
+    const int co0 = cb * CB, ci0 = ib * CB;
+    const int cow = min(CB, ((a.Cout - co0) + 31) & ~31), ciw = min(CB, a.Cin - ci0);
     const int nct = cow / 32, nit = ciw / 32, npairs = nct * nit;
     const int xv = ciw / 8, dv = cow / 8;                   // 16-byte vectors per row of each operand
     const int nx = PW_ROWS * xv, nitems = nx + PW_ROWS * dv; // <= 2048 vectors per chunk
@@ -388,14 +389,19 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bx, const int
     }
 }
 
+template <int RS>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    pw_body<PW_RS, 4, 8>(a, blockIdx.x, blockIdx.y, smem);
+    if constexpr (RS == PW_RS_NARROW) pw_body<RS, 1, 4>(a, blockIdx.x, blockIdx.y, smem);
+    else pw_body<RS, 4, 8>(a, blockIdx.x, blockIdx.y, smem);
 }
 
-// RS = PW_RS_NARROW: a launch of narrow problems only.  These are the pointwise convolutions of the large-image stages (few
-// channels, hundreds of thousands of rows): bound by the loads in flight, and a workgroup's stage is sized by its row stride,
-// so the narrow stride doubles the workgroups a CU holds.
+// RS = PW_RS_NARROW: workgroups of 64 x 64 channels (a quarter of the registers, half the LDS: four workgroups per CU).  Two
+// kinds of problem go there (wgrad_plan): the pointwise convolutions of the large-image stages (few channels, hundreds of
+// thousands of rows), which are bound by the loads in flight; and wider problems whose 128 x 128 blocking would give fewer
+// than 512 workgroups - a workgroup has one chunk of loads in flight, so a launch of 34 .. 144 workgroups (what the deep
+// stages of a 32x32 network give) runs at the latency of its chunks while most CUs idle.  Four times the workgroups read each
+// operand twice (from L2: these tensors are a few MB) and finish in about half the time.
 template <int RS>
 __global__ __launch_bounds__(256) void pw_wgrad_group_kernel(const PwArgs* __restrict__ tab, const int* __restrict__ first, const int n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -429,7 +435,7 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s
 struct WgradPlan {
     WgradArgs a;
     PwArgs pw;
-    bool pointwise;
+    bool pointwise, pw_narrow;
     int nco, maxi;
     dim3 grid;
     size_t lds;
@@ -454,28 +460,37 @@ static int wgrad_plan(const ddpm_wgrad_desc* d, WgradPlan& p) {
     const int slices = d->kind == CONV_1X1 ? 1 : d->kind == CONVT_2X2_S2 ? 4 : 9;
     a.dw_numel = (long long)slices * d->Cout * Cin;
     p.pointwise = d->kind == CONV_1X1 && d->C1 == 0 && !d->in_add && Cin % 32 == 0;
+    p.pw_narrow = false;
     if (p.pointwise) {
         PwArgs& w = p.pw;
         w.x = a.in0; w.dy = a.dy; w.in_mask = a.in_mask; w.in_mask_scale = a.in_mask_scale;
         w.dw = a.dw; w.part = a.part; w.dw_numel = a.dw_numel;
         w.R = (long long)d->N * d->IH * d->IW;
         w.Cin = Cin; w.Cout = d->Cout; w.dy_cs = d->dy_cs;
-        const int ncb = (d->Cout + 127) / 128;
-        w.nib = (Cin + 127) / 128;
-        const long long other = (long long)ncb * w.nib;
         const long long tiles = (w.R + 127) / 128;
-        long long msplit = 512 / other;
-        if (d->tiles_per_split > 0) {
-            const long long want = (tiles + d->tiles_per_split - 1) / d->tiles_per_split;
-            if (want < msplit) msplit = want;
+        long long msplit = 0, other = 0;
+        p.pw_narrow = Cin <= PW_NARROW_MAX && d->Cout <= PW_NARROW_MAX;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int cb = p.pw_narrow ? PW_NARROW_MAX : 128;
+            const int ncb = (d->Cout + cb - 1) / cb;
+            w.nib = (Cin + cb - 1) / cb;
+            other = (long long)ncb * w.nib;
+            msplit = 512 / other;
+            if (d->tiles_per_split > 0) {
+                const long long want = (tiles + d->tiles_per_split - 1) / d->tiles_per_split;
+                if (want < msplit) msplit = want;
+            }
+            if (msplit < 1) msplit = 1;
+            if (msplit > tiles) msplit = tiles;
+            w.rows_per_split = (tiles + msplit - 1) / msplit * 128;
+            msplit = (w.R + w.rows_per_split - 1) / w.rows_per_split;
+            // too few workgroups for the machine in blocks of 128 x 128 channels: blocks of 64 x 64 (see pw_wgrad_group_kernel)
+            if (p.pw_narrow || msplit * other >= 512) break;
+            p.pw_narrow = true;
         }
-        if (msplit < 1) msplit = 1;
-        if (msplit > tiles) msplit = tiles;
-        w.rows_per_split = (tiles + msplit - 1) / msplit * 128;
-        msplit = (w.R + w.rows_per_split - 1) / w.rows_per_split;
         w.gx = (int)msplit;
         p.grid = dim3((unsigned)msplit, (unsigned)other, 1);
-        p.lds = PW_LDS;
+        p.lds = p.pw_narrow ? PW_LDS_NARROW : PW_LDS;
         p.nco = p.maxi = 0;
         a.gx = (int)msplit; a.gy = (int)other;
         return DDPM_OK;
@@ -527,13 +542,17 @@ extern "C" int ddpm_conv_wgrad(const ddpm_wgrad_desc* d, ddpm_stream_t stream_) 
     if (int rc = wgrad_plan(d, p)) return rc;            // (also validates the descriptor)
     if (const int rc = ddpm_conv_wgrad_pipe_try(d, stream)) return rc > 0 ? DDPM_OK : DDPM_EHIP;
     if (p.pointwise) {
+        if (p.pw_narrow) {
+            hipLaunchKernelGGL(pw_wgrad_kernel<PW_RS_NARROW>, p.grid, dim3(256), PW_LDS_NARROW, stream, p.pw);
+            return ddpm_check_launch("pw_wgrad (narrow)");
+        }
         static bool attr = false;
         if (!attr) {
-            if (hipFuncSetAttribute((const void*)pw_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)pw_wgrad_kernel<PW_RS>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS) != hipSuccess)
                 return ddpm_check_launch("wgrad: raise dynamic LDS limit");
             attr = true;
         }
-        hipLaunchKernelGGL(pw_wgrad_kernel, p.grid, dim3(256), PW_LDS, stream, p.pw);
+        hipLaunchKernelGGL(pw_wgrad_kernel<PW_RS>, p.grid, dim3(256), PW_LDS, stream, p.pw);
         return ddpm_check_launch("pw_wgrad");
     }
     const WgradArgs& a = p.a;
@@ -582,7 +601,7 @@ extern "C" int ddpm_conv_wgrad_group_plan(const ddpm_wgrad_desc* descs, int n, v
         variant_of[i] = -1;
         for (int v = 0; v < WG_VARIANTS; ++v)
             if (plans[i].nco == kVariantNco[v] && plans[i].maxi == kVariantMaxi[v]) variant_of[i] = v;
-        if (plans[i].pointwise) variant_of[i] = (plans[i].pw.Cin <= PW_NARROW_MAX && plans[i].pw.Cout <= PW_NARROW_MAX) ? 6 : 5;
+        if (plans[i].pointwise) variant_of[i] = plans[i].pw_narrow ? 6 : 5;
         DDPM_REQUIRE(variant_of[i] >= 0, "wgrad group: no kernel for nco=%d items/wave=%d", plans[i].nco, plans[i].maxi);
     }
     long long off = align16(sizeof(WgradGroupHeader));
