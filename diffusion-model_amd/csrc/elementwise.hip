@@ -805,11 +805,14 @@ extern "C" int ddpm_dropout_masks(uint8_t* bytes, const int64_t* offsets, int ns
     DDPM_REQUIRE(keep > 0.f && keep <= 1.f, "dropout_masks: keep probability %f out of range", (double)keep);
     DDPM_REQUIRE(((uintptr_t)bytes & 15) == 0, "dropout_masks: the bit buffer must be 16-byte aligned");
     const unsigned thresh = (unsigned)(keep * 65536.0f + 0.5f);
-    // At most two workgroups per CU: the kernel is ALU bound (70 us against 62 us with every wave slot taken, for 22 MB of
-    // bits), and it usually runs on a side stream beside latency-bound kernels whose workgroups must still find free
-    // wave slots (a full-size grid delayed the first kernels of a training step by ~50 us).
+    // At most one workgroup per CU: the kernel is ALU bound (70 us with two per CU against 62 us with every wave slot taken, for
+    // 22 MB of bits), and it usually runs on a side stream beside latency-bound kernels whose workgroups must still find free
+    // wave slots (a full-size grid delayed the first kernels of a training step by ~50 us; one workgroup per CU instead of two
+    // takes twice as long beside them and costs the step 10 us less; half of that again costs more).  DDPM_MASK_GRID: a
+    // measurement switch for this bound.
     int mgrid = stream_grid((total_bytes + 15) / 16, 256);
-    if (mgrid > 512) mgrid = 512;
+    static const int cap = [] { const char* e = getenv("DDPM_MASK_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    if (mgrid > cap) mgrid = cap;
     hipLaunchKernelGGL(dropout_masks_kernel, dim3(mgrid), dim3(256), 0, stream, bytes,
                        (const long long*)offsets, nsites, (long long)total_bytes, thresh, (const unsigned long long*)seed);
     return ddpm_check_launch("dropout_masks");
