@@ -118,6 +118,17 @@ class GraphedTrainStep:
         return self.loss
 
 
+def _merge_ranges(ranges):
+    """sorted union of half-open element ranges, touching ones joined"""
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and lo <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
+
+
 class PipelinedTrainStep:
     """The training step as a small pipeline of HIP graphs on two streams, driving the engine directly (no autograd node).
 
@@ -181,7 +192,7 @@ class PipelinedTrainStep:
         # data parallel with the standard four phases (cuts: before encoder stage e, before the decoder's input, before decoder
         # stage d): the encoder's half of the gradients is exchanged in two parts, see _leaf
         self._enc_split, self._late_done, self._enc_late, self._enc_rest = None, False, [], []
-        self._early, self._early_done = False, 0
+        self._early, self._early_late, self._early_done = False, False, 0
         cuts = self.eng._phase_cuts(len(self.eng.spec.stages))
         enc_cuts = [c for c in cuts if c.startswith("enc") and c[3:].isdigit()]
         four = len(cuts) == 3 and len(enc_cuts) == 1 and "dec" in cuts
@@ -193,7 +204,10 @@ class PipelinedTrainStep:
         # (2.707 -> 2.695 ms at 32x32x1, 4.99 -> 4.96 ms at 64x64x3).  DDPM_EARLY_ADAM=2 also updates the deep encoder stages
         # one phase before the end: measured slower, that phase's leaf work is what the last phase's leaf work waits for.
         self._early = not self._sep_adam and four and os.environ.get("DDPM_EARLY_ADAM", "1") != "0"
-        if self._early and os.environ.get("DDPM_EARLY_ADAM", "1") == "2":
+        self._early_late = self._early and os.environ.get("DDPM_EARLY_ADAM", "1") == "2"
+        if self._early:
+            # (the gradients of the deep encoder stages go to torch layout one phase before the end either way: that launch is
+            # then not part of the step's tail)
             self._enc_split = int(enc_cuts[0][3:])
         self._fuse_head = os.environ.get("DDPM_FUSE_HEAD", "1") != "0"
         self.K, self.mid = self.eng.phase_layout()      # mid: the phase after which the decoder half of the gradients is final
@@ -303,7 +317,7 @@ class PipelinedTrainStep:
             # end.  Data parallel: their exchange travels during the last phase, which leaves a few hundred KB for the end
             self._enc_late = g.unpack_where("encoder late", self._is_enc_late)
             self._late_done = True
-            if early and self._early_done == 1:
+            if early and self._early_done == 1 and self._early_late:
                 self._adam_piece(self._enc_late, "encoder late", self._is_enc_late, False)
         if last:
             if not self._ready[self.mid]:               # first pass of a shape: everything becomes final here
@@ -321,7 +335,8 @@ class PipelinedTrainStep:
                 self._adam_piece(self._enc_rest, "encoder rest", self._is_enc_rest, True)
                 self.eng.commit_masks()
             elif self._early_done == 1:
-                self._adam_piece([self._ranges[1]], "not decoder", lambda n: not n.startswith("decoder."), True)
+                rest = _merge_ranges(self._enc_late + self._enc_rest) if self._late_done else [self._ranges[1]]
+                self._adam_piece(rest, "not decoder", lambda n: not n.startswith("decoder."), True)
                 self.eng.commit_masks()
             elif not self._sep_adam:
                 # single GPU: nothing comes between the last gradient and the optimizer, so the update rides at the end
