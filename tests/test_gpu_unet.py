@@ -432,7 +432,7 @@ def test_overlapped_train_step_matches_plain_step(dev):
         crit = ELBOLoss("mse")
         x0 = (hash_uniform((8, 1, 32, 32), 5) * 2 - 1).to(dev)
         out = []
-        for mode in ("plain", "dp2", "dp5", "dp9", "single4"):
+        for mode in ("plain", "dp2", "dp4", "dp5", "dp9", "single4"):
             torch.manual_seed(77)
             m, _, _ = build(dev, 1, "gelu", drop_p=0.0)
             m.train()
@@ -444,8 +444,11 @@ def test_overlapped_train_step_matches_plain_step(dev):
             else:
                 red = GradReducer(list(m.parameters()), world=2)      # world=2: the collective path is taken on the one-rank group
                 step = graphs.OverlappedTrainStep(m, crit, opt, x0, red, phases=int(mode[2]))
-                assert step.graphs is not None and step._ranges[0][1] == red.total and step._ranges[1][0] == 0
-                assert step._ranges[0][0] == step._ranges[1][1]
+                assert step.graphs is not None and step._ranges[0][1] == red.total
+                if mode == "dp4":       # the default: four phases, the encoder's share of the gradients travels in two parts
+                    assert step._late_done and step._enc_late and step._enc_rest
+                else:
+                    assert step._ranges[1][0] == 0 and step._ranges[0][0] == step._ranges[1][1]
             losses = [step.replay().item() for _ in range(4)]
             assert all(math.isfinite(v) for v in losses)
             out.append((losses, [p.detach().clone() for p in m.parameters()], [k for k, _ in m.named_parameters()]))
